@@ -1,0 +1,385 @@
+"""ctypes bindings for the TEST-ONLY checkers.
+
+* ``oracle``  -> oracle/_build/libopv_oracle.so  (our plain-C restatement, always available:
+                 built on demand with gcc)
+* ``ref``     -> oracle/_ref/libopv_ref.so       (window onto the compiled reference classes;
+                 present only where oracle/Makefile could see /root/reference, or where the
+                 prebuilt file travelled with the snapshot)
+
+Nothing in the product imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+ORACLE_DIR = ROOT / "oracle"
+
+SPS = 40
+FRAME_BYTES = 134
+FRAME_BITS = 1072
+CODED_BITS = 2144
+FRAME_SYMBOLS = 2168
+CHUNK_SAMPLES = 86720
+
+EVENT_DTYPE = np.dtype(
+    [("kind", "<i4"), ("count", "<i4"), ("sym_idx", "<u8"), ("corr", "<f8"), ("raw", "<f8")], align=True
+)
+EV_NAMES = {1: "HUNT_TO_VERIFY", 2: "VERIFY_TO_LOCK", 3: "SYNC_OK", 4: "SYNC_MISS", 5: "LOST_LOCK"}
+
+
+def build_oracle():
+    subprocess.run(["make", "-s", "-C", str(ORACLE_DIR), "oracle"], check=True)
+    return ORACLE_DIR / "_build" / "libopv_oracle.so"
+
+
+class _RxCfg(C.Structure):
+    _fields_ = [("streaming", C.c_int), ("have_init_offset", C.c_int), ("init_offset", C.c_double),
+                ("afc_alpha", C.c_double)]
+
+
+class _RxOut(C.Structure):
+    _fields_ = [
+        ("frames", C.c_void_p), ("metrics", C.c_void_p), ("quality", C.c_void_p), ("frame_sym", C.c_void_p),
+        ("cap_frames", C.c_size_t),
+        ("soft", C.c_void_p), ("cap_soft", C.c_size_t),
+        ("events", C.c_void_p), ("cap_events", C.c_size_t),
+        ("chunk_state", C.c_void_p), ("cap_chunks", C.c_size_t),
+        ("n_frames", C.c_size_t), ("n_perfect", C.c_size_t), ("n_soft", C.c_size_t), ("n_events", C.c_size_t),
+        ("n_chunks", C.c_size_t),
+        ("est_offset", C.c_double), ("final_freq_offset", C.c_double), ("final_timing_freq", C.c_double),
+        ("final_state", C.c_int),
+    ]
+
+
+class _Demod(C.Structure):
+    _fields_ = [("freq_offset", C.c_double), ("phase_f1", C.c_double), ("phase_f2", C.c_double),
+                ("prev1_re", C.c_double), ("prev1_im", C.c_double), ("prev2_re", C.c_double),
+                ("prev2_im", C.c_double), ("afc_alpha", C.c_double), ("mu", C.c_double),
+                ("timing_freq", C.c_double), ("alpha_timing", C.c_double), ("beta_timing", C.c_double),
+                ("leftover", C.c_size_t)]
+
+
+def _iq(a):
+    a = np.ascontiguousarray(a, dtype=np.int16).reshape(-1)
+    assert a.size % 2 == 0
+    return a
+
+
+class Oracle:
+    """The plain-C restatement (oracle/opv_oracle.c)."""
+
+    def __init__(self):
+        self.lib = C.CDLL(str(build_oracle()))
+        L = self.lib
+        L.oro_modulated_len.restype = C.c_size_t
+        L.oro_modulated_len.argtypes = [C.c_size_t]
+        L.oro_modulate_frames.restype = C.c_size_t
+        L.oro_modulate_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.oro_bert_frame.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.oro_encode_frame.argtypes = [C.c_void_p, C.c_void_p]
+        L.oro_lfsr_table.argtypes = [C.c_void_p]
+        L.oro_base40_encode.argtypes = [C.c_char_p, C.c_void_p]
+        L.oro_estimate_offset.restype = C.c_double
+        L.oro_estimate_offset.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.oro_demod_init.argtypes = [C.c_void_p]
+        L.oro_demodulate.restype = C.c_size_t
+        L.oro_demodulate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.oro_deinterleave_addr.restype = C.c_size_t
+        L.oro_deinterleave_addr.argtypes = [C.c_size_t]
+        L.oro_viterbi.restype = C.c_int
+        L.oro_viterbi.argtypes = [C.c_void_p, C.c_void_p]
+        L.oro_frame_decode.restype = C.c_int
+        L.oro_frame_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oro_receive.restype = C.c_int
+        L.oro_receive.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+
+    # ---- transmit ----
+    def bert_frames(self, n, callsign="W5NYV", token=0xBBAADD, first=0):
+        out = np.zeros((n, FRAME_BYTES), np.uint8)
+        for k in range(n):
+            self.lib.oro_bert_frame(callsign.encode(), token, first + k, out[k].ctypes.data)
+        return out
+
+    def modulate(self, frames):
+        frames = np.ascontiguousarray(frames, np.uint8).reshape(-1, FRAME_BYTES)
+        n = self.lib.oro_modulated_len(len(frames))
+        iq = np.empty(2 * n, np.int16)
+        w = self.lib.oro_modulate_frames(frames.ctypes.data, len(frames), iq.ctypes.data)
+        assert w == n
+        return iq
+
+    def encode_frame(self, payload):
+        payload = np.ascontiguousarray(payload, np.uint8)
+        out = np.zeros(CODED_BITS, np.uint8)
+        self.lib.oro_encode_frame(payload.ctypes.data, out.ctypes.data)
+        return out
+
+    def lfsr_table(self):
+        out = np.zeros(FRAME_BYTES, np.uint8)
+        self.lib.oro_lfsr_table(out.ctypes.data)
+        return out
+
+    def base40(self, callsign):
+        out = np.zeros(6, np.uint8)
+        self.lib.oro_base40_encode(callsign.encode(), out.ctypes.data)
+        return out
+
+    # ---- receive pieces ----
+    def estimate_offset(self, iq, energies=False):
+        iq = _iq(iq)
+        e = np.zeros(134, np.float64)
+        r = self.lib.oro_estimate_offset(iq.ctypes.data, iq.size // 2, e.ctypes.data)
+        return (r, e) if energies else r
+
+    def new_demod(self):
+        d = _Demod()
+        self.lib.oro_demod_init(C.byref(d))
+        return d
+
+    def demodulate(self, d, iq):
+        iq = _iq(iq)
+        n = iq.size // 2
+        soft = np.empty(n // 38 + 8, np.float64)
+        ns = self.lib.oro_demodulate(C.byref(d), iq.ctypes.data, n, soft.ctypes.data, soft.size)
+        return soft[:ns].copy()
+
+    def deinterleave_perm(self):
+        return np.array([self.lib.oro_deinterleave_addr(i) for i in range(CODED_BITS)], np.uint16)
+
+    def viterbi(self, q):
+        q = np.ascontiguousarray(q, np.int32)
+        bits = np.zeros(FRAME_BITS, np.uint8)
+        m = self.lib.oro_viterbi(q.ctypes.data, bits.ctypes.data)
+        return m, bits
+
+    def frame_decode(self, soft):
+        soft = np.ascontiguousarray(soft, np.float64)
+        assert soft.size == CODED_BITS
+        out = np.zeros(FRAME_BYTES, np.uint8)
+        q = np.zeros(CODED_BITS, np.int32)
+        de = np.zeros(CODED_BITS, np.int32)
+        bits = np.zeros(FRAME_BITS, np.uint8)
+        m = self.lib.oro_frame_decode(soft.ctypes.data, out.ctypes.data, q.ctypes.data, de.ctypes.data,
+                                      bits.ctypes.data)
+        return dict(metric=m, frame=out, q=q, deint=de, bits=bits)
+
+    # ---- whole receiver ----
+    def receive(self, iq, streaming=True, init_offset=None, afc_alpha=0.001, want_soft=True):
+        iq = _iq(iq)
+        n = iq.size // 2
+        cap_frames = n // (FRAME_SYMBOLS * 38) + 8
+        cap_soft = (n // 38 + 64) if want_soft else 0
+        frames = np.zeros((cap_frames, FRAME_BYTES), np.uint8)
+        metrics = np.zeros(cap_frames, np.int32)
+        quality = np.zeros(cap_frames, np.float64)
+        fsym = np.zeros(cap_frames, np.uint64)
+        soft = np.zeros(max(cap_soft, 1), np.float64)
+        events = np.zeros(4 * cap_frames + 64, EVENT_DTYPE)
+        cap_chunks = n // 80000 + 4
+        chunks = np.zeros((cap_chunks, 5), np.float64)
+        cfg = _RxCfg(int(streaming), int(init_offset is not None), float(init_offset or 0.0), afc_alpha)
+        out = _RxOut()
+        out.frames, out.metrics, out.quality, out.frame_sym = (frames.ctypes.data, metrics.ctypes.data,
+                                                               quality.ctypes.data, fsym.ctypes.data)
+        out.cap_frames = cap_frames
+        out.soft = soft.ctypes.data if want_soft else None
+        out.cap_soft = cap_soft
+        out.events, out.cap_events = events.ctypes.data, events.size
+        out.chunk_state, out.cap_chunks = chunks.ctypes.data, cap_chunks
+        rc = self.lib.oro_receive(iq.ctypes.data, n, C.byref(cfg), C.byref(out))
+        assert rc == 0
+        nf = out.n_frames
+        assert nf <= cap_frames and out.n_events <= events.size and out.n_chunks <= cap_chunks
+        return dict(
+            frames=frames[:nf].copy(), metrics=metrics[:nf].copy(), quality=quality[:nf].copy(),
+            frame_sym=fsym[:nf].copy(), n_perfect=out.n_perfect,
+            soft=soft[:out.n_soft].copy() if want_soft else None, n_soft=out.n_soft,
+            events=events[:out.n_events].copy(), chunks=chunks[:out.n_chunks].copy(),
+            est_offset=out.est_offset, final_freq_offset=out.final_freq_offset,
+            final_timing_freq=out.final_timing_freq, final_state=out.final_state,
+        )
+
+
+def format_events(events):
+    """Render tracker events exactly as SyncTracker::process prints them
+    (reference src/opv-demod.cpp:651,677,695,699,705)."""
+    lines = []
+    for e in events:
+        k, idx = int(e["kind"]), int(e["sym_idx"])
+        if k == 1:
+            lines.append("[%d] HUNTING→VERIFYING (corr=%.3f, raw=%.0f)" % (idx, e["corr"], e["raw"]))
+        elif k == 2:
+            lines.append("[%d] VERIFYING→LOCKED (frame %d)" % (idx, e["count"]))
+        elif k == 3:
+            lines.append("[%d] LOCKED: sync OK (corr=%.3f)" % (idx, e["corr"]))
+        elif k == 4:
+            lines.append("[%d] LOCKED: sync MISS #%d (corr=%.3f)" % (idx, e["count"], e["corr"]))
+        elif k == 5:
+            lines.append("[%d] LOCKED→HUNTING (lost lock)" % idx)
+    return lines
+
+
+# ---------------------------------------------------------------------------------------
+class Reference:
+    """Window onto the compiled reference classes (oracle/_ref/libopv_ref.so)."""
+
+    @staticmethod
+    def available():
+        return (ORACLE_DIR / "_ref" / "libopv_ref.so").exists()
+
+    def __init__(self):
+        self.lib = C.CDLL(str(ORACLE_DIR / "_ref" / "libopv_ref.so"))
+        L = self.lib
+        for f in ("ref_demod_create", "ref_tracker_create"):
+            getattr(L, f).restype = C.c_void_p
+        for f in ("ref_demod_freq_offset", "ref_demod_timing_freq", "ref_demod_estimate_offset"):
+            getattr(L, f).restype = C.c_double
+        for f in ("ref_demod_leftover", "ref_demod_demodulate", "ref_deinterleave_addr", "ref_log_take"):
+            getattr(L, f).restype = C.c_size_t
+        L.ref_demod_destroy.argtypes = [C.c_void_p]
+        L.ref_demod_set_freq_offset.argtypes = [C.c_void_p, C.c_double]
+        L.ref_demod_set_afc.argtypes = [C.c_void_p, C.c_double]
+        L.ref_demod_freq_offset.argtypes = [C.c_void_p]
+        L.ref_demod_timing_freq.argtypes = [C.c_void_p]
+        L.ref_demod_leftover.argtypes = [C.c_void_p]
+        L.ref_demod_estimate_offset.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ref_demod_demodulate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.ref_tracker_destroy.argtypes = [C.c_void_p]
+        L.ref_tracker_state.argtypes = [C.c_void_p]
+        L.ref_tracker_process.argtypes = [C.c_void_p, C.c_double, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.ref_deinterleave_addr.argtypes = [C.c_size_t]
+        L.ref_viterbi.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_frame_decode.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_log_take.argtypes = [C.c_void_p, C.c_size_t]
+
+    def take_log(self):
+        buf = C.create_string_buffer(1 << 22)
+        n = self.lib.ref_log_take(buf, len(buf))
+        return buf.raw[:min(n, len(buf))].decode("utf-8")
+
+    def estimate_offset(self, iq):
+        iq = _iq(iq)
+        h = self.lib.ref_demod_create()
+        r = self.lib.ref_demod_estimate_offset(h, iq.ctypes.data, iq.size // 2)
+        self.lib.ref_demod_destroy(h)
+        return r
+
+    def frame_decode(self, soft):
+        soft = np.ascontiguousarray(soft, np.float64)
+        out = np.zeros(FRAME_BYTES, np.uint8)
+        m = self.lib.ref_frame_decode(soft.ctypes.data, out.ctypes.data)
+        return m, out
+
+    def viterbi(self, q):
+        q = np.ascontiguousarray(q, np.int32)
+        bits = np.zeros(FRAME_BITS, np.uint8)
+        m = self.lib.ref_viterbi(q.ctypes.data, bits.ctypes.data)
+        return m, bits
+
+    def deinterleave_perm(self):
+        return np.array([self.lib.ref_deinterleave_addr(i) for i in range(CODED_BITS)], np.uint16)
+
+    def receive(self, iq, streaming=True, init_offset=None, afc_alpha=0.001):
+        """Drive the reference classes the way the reference's main() does
+        (streaming src/opv-demod.cpp:995-1113, batch :1132-1206)."""
+        iq = _iq(iq)
+        n = iq.size // 2
+        L = self.lib
+        self.take_log()
+        dm = L.ref_demod_create()
+        tr = L.ref_tracker_create()
+        softs, frames, metrics, quality, fsym, chunks = [], [], [], [], [], []
+        est = float("nan")
+        payload = np.zeros(CODED_BITS, np.float64)
+        q = C.c_double(0)
+        total = 0
+
+        def feed(s):
+            nonlocal total
+            for i, v in enumerate(s):
+                if L.ref_tracker_process(tr, float(v), total + i, payload.ctypes.data, C.byref(q)):
+                    m, fr = self.frame_decode(payload)
+                    if m >= 0:
+                        frames.append(fr)
+                        metrics.append(m)
+                        quality.append(q.value)
+                        fsym.append(total + i)
+            total += len(s)
+
+        def demod(view):
+            buf = np.empty(view.size // 2 // 38 + 8, np.float64)
+            ns = L.ref_demod_demodulate(dm, view.ctypes.data, view.size // 2, buf.ctypes.data, buf.size)
+            chunks.append([L.ref_demod_freq_offset(dm), L.ref_demod_timing_freq(dm), float("nan"),
+                           float(L.ref_demod_leftover(dm)), float(ns)])
+            return buf[:ns].copy()
+
+        if streaming:
+            if init_offset is not None:
+                L.ref_demod_set_freq_offset(dm, float(init_offset))
+            L.ref_demod_set_afc(dm, afc_alpha)
+            start, first = 0, True
+            while n - start >= CHUNK_SAMPLES:
+                view = iq[2 * start: 2 * (start + CHUNK_SAMPLES)]
+                if first:
+                    if init_offset is None:
+                        est = L.ref_demod_estimate_offset(dm, view.ctypes.data, CHUNK_SAMPLES)
+                        L.ref_demod_set_freq_offset(dm, est)
+                    first = False
+                s = demod(view)
+                softs.append(s)
+                feed(s)
+                lo = L.ref_demod_leftover(dm)
+                start += CHUNK_SAMPLES - lo if 0 < lo < CHUNK_SAMPLES else CHUNK_SAMPLES
+            if n > start:
+                s = demod(iq[2 * start:])
+                softs.append(s)
+                feed(s)
+        else:
+            est = L.ref_demod_estimate_offset(dm, iq.ctypes.data, n)
+            L.ref_demod_set_freq_offset(dm, est)
+            L.ref_demod_set_afc(dm, afc_alpha)
+            s = demod(iq)
+            softs.append(s)
+            feed(s)
+        res = dict(
+            frames=np.array(frames, np.uint8).reshape(-1, FRAME_BYTES), metrics=np.array(metrics, np.int32),
+            quality=np.array(quality), frame_sym=np.array(fsym, np.uint64),
+            soft=np.concatenate(softs) if softs else np.zeros(0), chunks=np.array(chunks).reshape(-1, 5),
+            est_offset=est, final_freq_offset=L.ref_demod_freq_offset(dm),
+            final_timing_freq=L.ref_demod_timing_freq(dm), final_state=L.ref_tracker_state(tr),
+            log=self.take_log(),
+        )
+        L.ref_demod_destroy(dm)
+        L.ref_tracker_destroy(tr)
+        return res
+
+
+def ref_binary(name):
+    p = ORACLE_DIR / "_ref" / name
+    return p if p.exists() else None
+
+
+# ---------------------------------------------------------------------------------------
+def impair(iq, amp=2000.0, f0_hz=0.0, ebn0_db=None, seed=1, full_scale=16383.0):
+    """Seeded channel model for the noisy configurations: rescale to
+    amplitude `amp`, rotate by exp(j 2 pi f0 n / Fs), add complex AWGN with total variance
+    80*amp^2 / 10^(EbN0/10) (Eb = 2 Es, Es = 40 amp^2), round to nearest, clip to int16.
+    The reference has no channel model; this tool DEFINES the inputs of those configs."""
+    iq = _iq(iq)
+    z = (iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)) * (amp / full_scale)
+    n = np.arange(z.size, dtype=np.float64)
+    if f0_hz:
+        z = z * np.exp(2j * np.pi * f0_hz * n / 2168000.0)
+    if ebn0_db is not None:
+        rng = np.random.default_rng(seed)
+        var = 80.0 * amp * amp / (10.0 ** (ebn0_db / 10.0))
+        sd = np.sqrt(var / 2.0)
+        z = z + sd * (rng.standard_normal(z.size) + 1j * rng.standard_normal(z.size))
+    out = np.empty(2 * z.size, np.int16)
+    out[0::2] = np.clip(np.rint(z.real), -32768, 32767).astype(np.int16)
+    out[1::2] = np.clip(np.rint(z.imag), -32768, 32767).astype(np.int16)
+    return out
