@@ -1,0 +1,179 @@
+/* include/opv_demod.h — C ABI of the MI355X-native OPV MSK receive chain.
+ *
+ * This is the drop-in boundary. The reference (OpenResearchInstitute/opv-cxx-demod) has no
+ * library/plugin API: its hot path sits behind three C++ objects that only main() uses
+ * (src/opv-demod.cpp:999-1001, :1164, :1182-1183) and behind the `opv-demod` process
+ * contract. Each entry point below names the reference interface it replaces. All state
+ * lives in device memory owned by an opv_ctx; signatures carry plain pointers and sizes
+ * only. A context is not thread-safe; distinct contexts are independent.
+ *
+ * Return convention: 0 on success, negative OPV_E* on error (never a silent CPU fallback:
+ * if no HIP device / kernel image is usable, opv_create fails with OPV_ENODEV).
+ */
+#ifndef OPV_DEMOD_H
+#define OPV_DEMOD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPV_ABI_VERSION 1
+
+#define OPV_SAMPLES_PER_SYMBOL 40    /* src/opv-demod.cpp:39  */
+#define OPV_FRAME_BYTES 134          /* :49  */
+#define OPV_FRAME_BITS 1072          /* :50  */
+#define OPV_ENCODED_BITS 2144        /* :51  */
+#define OPV_FRAME_SYMBOLS 2168       /* :52  */
+#define OPV_CHUNK_SAMPLES 86720      /* :1012 streaming chunk = one frame of samples */
+
+enum {
+    OPV_OK = 0,
+    OPV_EINVAL = -1,   /* bad argument                                   */
+    OPV_ENODEV = -2,   /* no usable HIP device / kernels failed to load  */
+    OPV_ENOMEM = -3,   /* device or host allocation failed               */
+    OPV_ECAPACITY = -4,/* per-stream capacity (opv_cfg.max_samples) exceeded */
+    OPV_EHIP = -5,     /* a HIP runtime call failed (see opv_last_error) */
+    OPV_ESTATE = -6    /* call not valid in this state (e.g. push after flush) */
+};
+
+/* Sync tracker states (enum class SyncState, src/opv-demod.cpp:73). */
+enum { OPV_HUNTING = 0, OPV_VERIFYING = 1, OPV_LOCKED = 2 };
+
+/* One entry per stderr line SyncTracker::process prints (src/opv-demod.cpp:651,677,695,699,705). */
+enum {
+    OPV_EV_HUNT_TO_VERIFY = 1,
+    OPV_EV_VERIFY_TO_LOCK = 2,
+    OPV_EV_SYNC_OK = 3,
+    OPV_EV_SYNC_MISS = 4,
+    OPV_EV_LOST_LOCK = 5
+};
+
+/* Replaces the flag parsing of main() (src/opv-demod.cpp:944-974) for the flags that reach
+ * the hot path: -s, -o <hz>, -a <alpha>. (-c/-p select the coherent demodulator, which is
+ * out of scope; -q/-r only affect host printing.) */
+typedef struct opv_cfg {
+    int32_t streaming;        /* 1: -s chunked semantics (:995-1125); 0: batch (:1132-1216) */
+    int32_t have_init_offset; /* -o given: skip the offset search in streaming mode (:1004,:1031) */
+    double init_offset_hz;    /* -o value */
+    double afc_alpha;         /* -a value; 0.001 if <= 0 is NOT substituted: pass 0.001 for the default (:945) */
+    int32_t device;           /* HIP device ordinal */
+    int32_t keep_soft;        /* reserved (soft symbols are always retained in this version) */
+    uint64_t max_samples;     /* per-stream capacity in IQ samples (sizes the device logs) */
+} opv_cfg;
+
+/* Per decoded frame: what main() knows when it prints/writes a frame
+ * (src/opv-demod.cpp:1048-1062: metric, res.sync_quality, sym index of release). */
+typedef struct opv_frame_meta {
+    int32_t viterbi_metric;   /* ViterbiDecoder::decode return (:845); 0 == "perfect" (:910) */
+    int32_t reserved;
+    double sync_quality;      /* SyncTracker::Result::sync_quality (:611) */
+    uint64_t release_symbol;  /* global symbol index at which the frame was released (:1046) */
+    uint64_t payload_symbol;  /* global symbol index of the first payload symbol */
+} opv_frame_meta;
+
+typedef struct opv_event {
+    int32_t kind;             /* OPV_EV_* */
+    int32_t count;            /* frame number (VERIFY_TO_LOCK) or miss number (SYNC_MISS) */
+    uint64_t sym_idx;         /* the [%zu] printed by the reference */
+    double corr;              /* normalised correlation */
+    double raw;               /* raw correlation (HUNT_TO_VERIFY line) */
+} opv_event;
+
+/* What the status / summary lines of main() read (src/opv-demod.cpp:1080-1082,1117-1120). */
+typedef struct opv_stream_state {
+    double freq_offset_hz;    /* MSKDemodulatorAFC::get_freq_offset (:331) */
+    double timing_freq;       /* get_timing_freq (:332) */
+    double est_offset_hz;     /* estimate_offset result (:1032/:1166); NaN if it did not run */
+    double mu;                /* fractional timing carry (:343) */
+    uint64_t total_symbols;   /* symbols demodulated so far */
+    uint64_t total_samples;   /* samples consumed by completed demodulate() calls (:1027) */
+    uint64_t chunk_origin;    /* sample index at which the next chunk starts */
+    int32_t sync_state;       /* OPV_HUNTING / VERIFYING / LOCKED (:738) */
+    int32_t frames_released;  /* SyncTracker::get_total_frames (:739) */
+    int32_t frames_decoded;   /* frames with metric >= 0 (`decoded`, :1053) */
+    int32_t frames_perfect;   /* metric == 0 (`perfect`, :1054) */
+    int32_t n_chunks;         /* demodulate() calls made */
+    int32_t flushed;
+} opv_stream_state;
+
+typedef struct opv_ctx opv_ctx;
+
+/* ---- lifetime: replaces constructing MSKDemodulatorAFC + SyncTracker + FrameDecoder
+ *      (src/opv-demod.cpp:999-1001 / :1164,:1182-1183) for n_streams independent captures */
+int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg);
+void opv_destroy(opv_ctx* ctx);
+const char* opv_last_error(void);
+int opv_abi_version(void);
+
+/* ---- host-buffer path -----------------------------------------------------------------
+ * opv_push_iq replaces the stdin reader + chunker (src/opv-demod.cpp:1021-1026 streaming,
+ * :1132-1135 batch): host-endian interleaved int16 I,Q. The caller keeps ownership; the
+ * samples are copied to the stream's device buffer. Nothing is computed until opv_process. */
+int opv_push_iq(opv_ctx* ctx, int stream, const int16_t* iq_interleaved, size_t n_samples);
+/* EOF on a stream: enables the tail processing of :1088-1113 (streaming) or the single
+ * whole-capture demodulate of :1166-1173 (batch) at the next opv_process. */
+int opv_flush(opv_ctx* ctx, int stream);
+
+/* ---- device-resident path -------------------------------------------------------------
+ * Zero-copy variant of push+flush for captures already in HBM (bench, multi-stream
+ * servers): d_iq is a DEVICE pointer (16-byte aligned) to n_samples interleaved int16 IQ
+ * that must stay valid until the context is destroyed or the stream is reset. */
+int opv_attach_device_iq(opv_ctx* ctx, int stream, const int16_t* d_iq, size_t n_samples, int eof);
+
+/* Runs the hot path on everything that is ready, for all streams, in four launches on the
+ * context's HIP stream: offset search (estimate_offset :131-202), MSK front-end
+ * (demodulate :206-329 incl. the chunker :1026-1076), sync tracker (:615-736) and frame
+ * decode (FrameDecoder::decode :854-898). Asynchronous; opv_sync waits. */
+int opv_process(opv_ctx* ctx);
+int opv_sync(opv_ctx* ctx);
+/* Restores a stream to its freshly-created state (keeps buffers). */
+int opv_reset_stream(opv_ctx* ctx, int stream);
+
+/* ---- results --------------------------------------------------------------------------
+ * opv_pop_frames replaces the frame writer (src/opv-demod.cpp:1052-1062): frames whose
+ * decoder returned -1 (silent frame, :859) are skipped exactly as the reference skips
+ * them. Copies up to cap_frames not-yet-popped frames (134 B each, in release order) and
+ * their meta; returns the number copied or a negative error. Implies opv_sync. */
+long opv_pop_frames(opv_ctx* ctx, int stream, uint8_t* out134, size_t cap_frames, opv_frame_meta* meta);
+long opv_pop_events(opv_ctx* ctx, int stream, opv_event* out, size_t cap_events);
+int opv_get_state(opv_ctx* ctx, int stream, opv_stream_state* out);
+
+/* Device-side views for zero-copy consumers (RCCL gather of decoded frames): frames are
+ * [n_streams][frame_capacity][134] uint8, metrics [n_streams][frame_capacity] int32 (-1 =
+ * dropped, INT32_MIN = not decoded yet), counts [n_streams] int32 = frames released. */
+int opv_device_frames(opv_ctx* ctx, const uint8_t** d_frames, const int32_t** d_metrics,
+                      const int32_t** d_counts, size_t* frame_capacity);
+void* opv_hip_stream(opv_ctx* ctx);
+
+/* ---- parity taps (debug): the intermediates the 1e-5 contract is checked on ------------ */
+long opv_tap_soft(opv_ctx* ctx, int stream, uint64_t first_symbol, double* out, size_t cap);
+/* per demodulate() call: {freq_offset, timing_freq, mu, leftover, n_symbols} */
+long opv_tap_chunks(opv_ctx* ctx, int stream, double* out5, size_t cap_chunks);
+/* 134 candidate energies of the offset search in scan order (121 coarse, 13 fine) */
+int opv_tap_offset_energies(opv_ctx* ctx, int stream, double* out134);
+
+/* Stand-alone FrameDecoder::decode (src/opv-demod.cpp:854-898) on n_frames payloads of
+ * 2144 host doubles each. Optional taps: q (quantised, :862-866), deint (:869-871),
+ * bits (Viterbi hard decisions, :874-875). metrics[i] = path metric or -1. */
+int opv_decode_payloads(opv_ctx* ctx, const double* soft, size_t n_frames, uint8_t* out134,
+                        int32_t* metrics, int8_t* q, int8_t* deint, uint8_t* bits);
+
+/* ---- signal source (reference src/opv-mod.cpp) ---------------------
+ * Host-side, bit-identical to `opv-mod`: BERT frames (:339-361) and the whole
+ * encode->interleave->MSK chain incl. 100 trailing zero symbols (:473-529). */
+void opv_tx_bert_frame(const char* callsign, uint32_t token, uint32_t frame_num, uint8_t out134[OPV_FRAME_BYTES]);
+size_t opv_tx_modulated_samples(size_t n_frames);
+size_t opv_tx_modulate(const uint8_t* frames134, size_t n_frames, int16_t* iq_out);
+/* Device-side channel tool for synthetic multi-stream workloads:
+ * d_out[n] = clip(rint(gain * d_in[n] * exp(j 2 pi f0 n / Fs) + sigma * N(0,1)+jN(0,1))),
+ * noise from a counter-based generator keyed by (seed, n). d_in/d_out: device int16 IQ. */
+int opv_channel_device(opv_ctx* ctx, const int16_t* d_in, int16_t* d_out, size_t n_samples,
+                       double gain, double f0_hz, double sigma, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPV_DEMOD_H */

@@ -1,0 +1,483 @@
+// opv_capi.hip — the thin C-ABI HIP shim behind include/opv_demod.h.
+//
+// Owns device memory and the per-stream device contexts, stages host IQ, and launches the
+// four hot-path kernels on one HIP stream. There is NO CPU implementation of the hot path in
+// this library: without a usable HIP device opv_create fails with OPV_ENODEV.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/opv_demod.h"
+#include "opv_device.h"
+
+extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg);
+extern "C" __global__ void k_msk_frontend(OpvStream*, OpvGlobalCfg);
+extern "C" __global__ void k_sync_track(OpvStream*);
+extern "C" __global__ void k_frame_decode(OpvStream*);
+extern "C" __global__ void k_decode_payloads(const double*, uint32_t, uint8_t*, int32_t*, int8_t*, int8_t*, uint8_t*);
+extern "C" __global__ void k_channel(const int4*, int4*, uint64_t, double, double, double, uint64_t);
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                              \
+    do {                                                          \
+        hipError_t _e = (expr);                                   \
+        if (_e != hipSuccess) return fail(OPV_EHIP, #expr, _e);   \
+    } while (0)
+
+struct StreamIn {  // host -> device per-round update
+    const int16_t* iq;
+    uint64_t n_avail;
+    int32_t eof;
+    int32_t dirty;
+};
+
+__global__ void k_apply_inputs(OpvStream* streams, const StreamIn* in, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && in[i].dirty) {
+        streams[i].iq = in[i].iq;
+        streams[i].n_avail = in[i].n_avail;
+        streams[i].eof = in[i].eof;
+    }
+}
+
+__global__ void k_collect_counts(const OpvStream* streams, int32_t* counts, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t f = streams[i].n_frames < streams[i].cap_frames ? streams[i].n_frames : streams[i].cap_frames;
+        counts[i] = (int32_t)f;
+    }
+}
+
+__global__ void k_fill_i32(int32_t* p, int32_t v, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+struct HostStream {
+    int16_t* d_iq_owned = nullptr;  // push path buffer
+    size_t iq_cap = 0;              // samples
+    const int16_t* d_iq = nullptr;  // what the kernels read
+    uint64_t n_avail = 0;
+    int eof = 0;
+    bool dirty = false;
+    bool attached = false;
+    uint64_t last_round_avail = 0;
+    uint32_t popped = 0;        // frame records already handed out
+    uint32_t events_popped = 0;
+};
+
+}  // namespace
+
+struct opv_ctx {
+    int n_streams = 0;
+    opv_cfg cfg{};
+    hipStream_t stream = nullptr;
+    OpvStream* d_streams = nullptr;
+    StreamIn* d_in = nullptr;
+    std::vector<OpvStream> mirror;  // host copy, refreshed by refresh()
+    std::vector<OpvStream> initial; // as created (for reset)
+    std::vector<HostStream> hs;
+    // pooled logs
+    double* d_soft = nullptr;
+    OpvFrameRec* d_frec = nullptr;
+    OpvEventRec* d_events = nullptr;
+    double* d_chunks = nullptr;
+    uint8_t* d_frames = nullptr;
+    int32_t* d_metrics = nullptr;
+    int32_t* d_counts = nullptr;
+    uint64_t cap_soft = 0;
+    uint32_t cap_frames = 0, cap_events = 0, cap_chunks = 0;
+    bool mirror_valid = false;
+
+    int refresh() {
+        if (mirror_valid) return OPV_OK;
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipMemcpy(mirror.data(), d_streams, sizeof(OpvStream) * n_streams, hipMemcpyDeviceToHost));
+        mirror_valid = true;
+        return OPV_OK;
+    }
+};
+
+extern "C" const char* opv_last_error(void) { return g_err.c_str(); }
+extern "C" int opv_abi_version(void) { return OPV_ABI_VERSION; }
+
+extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
+    if (!out || !cfg || n_streams <= 0 || cfg->max_samples == 0) return fail(OPV_EINVAL, "opv_create: bad arguments");
+    if (cfg->max_samples >= (1ull << 31)) return fail(OPV_EINVAL, "opv_create: max_samples must be < 2^31");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(OPV_ENODEV, "no HIP device visible");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(OPV_ENODEV, "opv_cfg.device out of range");
+    HIPCHK(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(OPV_ENODEV, "device is not gfx950 (MI355X); this library carries gfx950 code objects only");
+
+    opv_ctx* c = new (std::nothrow) opv_ctx();
+    if (!c) return fail(OPV_ENOMEM, "host allocation failed");
+    c->n_streams = n_streams;
+    c->cfg = *cfg;
+    c->hs.resize(n_streams);
+    c->mirror.resize(n_streams);
+
+    const uint64_t M = cfg->max_samples;
+    c->cap_soft = M / 38 + 128;
+    c->cap_frames = (uint32_t)(M / (uint64_t)(OPV_FSYMS * 38) + 4);
+    c->cap_events = 4 * c->cap_frames + 64;
+    c->cap_chunks = (uint32_t)(M / 80000 + 4);
+
+    auto cleanup = [&](int code) { opv_destroy(c); return code; };
+#define HIPCHK_C(expr)                                                        \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) return cleanup(fail(_e == hipErrorOutOfMemory ? OPV_ENOMEM : OPV_EHIP, #expr, _e)); \
+    } while (0)
+
+    HIPCHK_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t S = (size_t)n_streams;
+    HIPCHK_C(hipMalloc(&c->d_streams, sizeof(OpvStream) * S));
+    HIPCHK_C(hipMalloc(&c->d_in, sizeof(StreamIn) * S));
+    HIPCHK_C(hipMalloc(&c->d_soft, sizeof(double) * c->cap_soft * S));
+    HIPCHK_C(hipMalloc(&c->d_frec, sizeof(OpvFrameRec) * c->cap_frames * S));
+    HIPCHK_C(hipMalloc(&c->d_events, sizeof(OpvEventRec) * c->cap_events * S));
+    HIPCHK_C(hipMalloc(&c->d_chunks, sizeof(double) * 5 * c->cap_chunks * S));
+    HIPCHK_C(hipMalloc(&c->d_frames, (size_t)OPV_FB * c->cap_frames * S));
+    HIPCHK_C(hipMalloc(&c->d_metrics, sizeof(int32_t) * c->cap_frames * S));
+    HIPCHK_C(hipMalloc(&c->d_counts, sizeof(int32_t) * S));
+    HIPCHK_C(hipMemsetAsync(c->d_frames, 0, (size_t)OPV_FB * c->cap_frames * S, c->stream));
+    HIPCHK_C(hipMemsetAsync(c->d_counts, 0, sizeof(int32_t) * S, c->stream));
+    k_fill_i32<<<256, 256, 0, c->stream>>>(c->d_metrics, INT32_MIN, (size_t)c->cap_frames * S);
+
+    for (size_t i = 0; i < S; ++i) {
+        OpvStream s;
+        std::memset(&s, 0, sizeof s);
+        s.soft = c->d_soft + c->cap_soft * i;
+        s.cap_soft = c->cap_soft;
+        s.frec = c->d_frec + (size_t)c->cap_frames * i;
+        s.events = c->d_events + (size_t)c->cap_events * i;
+        s.chunk_log = c->d_chunks + (size_t)5 * c->cap_chunks * i;
+        s.frames = c->d_frames + (size_t)OPV_FB * c->cap_frames * i;
+        s.metrics = c->d_metrics + (size_t)c->cap_frames * i;
+        s.cap_frames = c->cap_frames;
+        s.cap_events = c->cap_events;
+        s.cap_chunks = c->cap_chunks;
+        // demod.set_freq_offset(init_offset) only in streaming mode (ref :1004-1005)
+        s.freq_offset = (cfg->streaming && cfg->have_init_offset) ? cfg->init_offset_hz : 0.0;
+        s.afc_alpha = cfg->afc_alpha;  // set_afc_bandwidth (ref :1009 / :1172)
+        s.est_offset = NAN;
+        s.trk_state = OPV_HUNTING;
+        c->mirror[i] = s;
+    }
+    c->initial = c->mirror;
+    HIPCHK_C(hipMemcpyAsync(c->d_streams, c->mirror.data(), sizeof(OpvStream) * S, hipMemcpyHostToDevice, c->stream));
+    HIPCHK_C(hipStreamSynchronize(c->stream));
+    c->mirror_valid = true;
+    *out = c;
+    return OPV_OK;
+#undef HIPCHK_C
+}
+
+extern "C" void opv_destroy(opv_ctx* c) {
+    if (!c) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& h : c->hs)
+        if (h.d_iq_owned) (void)hipFree(h.d_iq_owned);
+    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_counts};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int check_stream(opv_ctx* c, int s) {
+    if (!c) return fail(OPV_EINVAL, "null context");
+    if (s < 0 || s >= c->n_streams) return fail(OPV_EINVAL, "stream index out of range");
+    return OPV_OK;
+}
+
+extern "C" int opv_push_iq(opv_ctx* c, int s, const int16_t* iq, size_t n) {
+    if (int r = check_stream(c, s)) return r;
+    HostStream& h = c->hs[s];
+    if (h.attached) return fail(OPV_ESTATE, "stream has an attached device capture");
+    if (h.eof) return fail(OPV_ESTATE, "push after flush");
+    if (n == 0) return OPV_OK;
+    if (!iq) return fail(OPV_EINVAL, "null IQ pointer");
+    if (h.n_avail + n > c->cfg.max_samples) return fail(OPV_ECAPACITY, "opv_cfg.max_samples exceeded");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (!h.d_iq_owned) {
+        h.iq_cap = c->cfg.max_samples;
+        HIPCHK(hipMalloc(&h.d_iq_owned, h.iq_cap * 4 + 16384));  // + slack for whole-tile reads
+        h.d_iq = h.d_iq_owned;
+    }
+    HIPCHK(hipMemcpyAsync(h.d_iq_owned + 2 * h.n_avail, iq, n * 4, hipMemcpyHostToDevice, c->stream));
+    // the caller keeps ownership of `iq`: the copy must have left the host buffer before we return
+    HIPCHK(hipStreamSynchronize(c->stream));
+    h.n_avail += n;
+    h.dirty = true;
+    return OPV_OK;
+}
+
+extern "C" int opv_flush(opv_ctx* c, int s) {
+    if (int r = check_stream(c, s)) return r;
+    c->hs[s].eof = 1;
+    c->hs[s].dirty = true;
+    return OPV_OK;
+}
+
+extern "C" int opv_attach_device_iq(opv_ctx* c, int s, const int16_t* d_iq, size_t n, int eof) {
+    if (int r = check_stream(c, s)) return r;
+    HostStream& h = c->hs[s];
+    if (h.d_iq_owned) return fail(OPV_ESTATE, "stream already has pushed samples");
+    if (!d_iq && n) return fail(OPV_EINVAL, "null device pointer");
+    if (((uintptr_t)d_iq & 15u) != 0) return fail(OPV_EINVAL, "device IQ pointer must be 16-byte aligned");
+    if (n > c->cfg.max_samples) return fail(OPV_ECAPACITY, "opv_cfg.max_samples exceeded");
+    if (h.attached && (d_iq != h.d_iq || n < h.n_avail)) return fail(OPV_ESTATE, "attached capture may only grow");
+    h.attached = true;
+    h.d_iq = d_iq;
+    h.n_avail = n;
+    h.eof = eof ? 1 : 0;
+    h.dirty = true;
+    return OPV_OK;
+}
+
+extern "C" int opv_process(opv_ctx* c) {
+    if (!c) return fail(OPV_EINVAL, "null context");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const int S = c->n_streams;
+    std::vector<StreamIn> in(S);
+    uint64_t max_new = 0;
+    bool any = false;
+    for (int i = 0; i < S; ++i) {
+        HostStream& h = c->hs[i];
+        in[i] = {h.d_iq, h.n_avail, h.eof, h.dirty ? 1 : 0};
+        if (h.dirty) any = true;
+        const uint64_t fresh = h.n_avail - h.last_round_avail;
+        if (fresh > max_new) max_new = fresh;
+        h.last_round_avail = h.n_avail;
+        h.dirty = false;
+    }
+    if (!any) return OPV_OK;
+    c->mirror_valid = false;
+    // pageable memcpy of a small array: staged by the runtime before the call returns
+    HIPCHK(hipMemcpyAsync(c->d_in, in.data(), sizeof(StreamIn) * S, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    OpvGlobalCfg g{c->cfg.streaming, c->cfg.have_init_offset, c->cfg.init_offset_hz};
+    k_apply_inputs<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_in, S);
+    k_offset_search<<<S, 256, 0, c->stream>>>(c->d_streams, g);
+    k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g);
+    k_sync_track<<<S, 64, 0, c->stream>>>(c->d_streams);
+    // frames a stream can release this round: new symbols / 2168 plus what was pending
+    uint64_t fr = max_new / (uint64_t)(OPV_FSYMS * 38) + 4;
+    if (fr > c->cap_frames) fr = c->cap_frames;
+    k_frame_decode<<<dim3((unsigned)fr, (unsigned)S), 64, 0, c->stream>>>(c->d_streams);
+    k_collect_counts<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_counts, S);
+    HIPCHK(hipGetLastError());
+    return OPV_OK;
+}
+
+extern "C" int opv_sync(opv_ctx* c) {
+    if (!c) return fail(OPV_EINVAL, "null context");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return OPV_OK;
+}
+
+extern "C" int opv_reset_stream(opv_ctx* c, int s) {
+    if (int r = check_stream(c, s)) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HostStream& h = c->hs[s];
+    int16_t* keep = h.d_iq_owned;
+    size_t cap = h.iq_cap;
+    h = HostStream();
+    h.d_iq_owned = keep;
+    h.iq_cap = cap;
+    h.d_iq = keep;
+    HIPCHK(hipMemcpy(c->d_streams + s, &c->initial[s], sizeof(OpvStream), hipMemcpyHostToDevice));
+    k_fill_i32<<<64, 256, 0, c->stream>>>(c->d_metrics + (size_t)c->cap_frames * s, INT32_MIN, c->cap_frames);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->mirror_valid = false;
+    return OPV_OK;
+}
+
+extern "C" long opv_pop_frames(opv_ctx* c, int s, uint8_t* out, size_t cap, opv_frame_meta* meta) {
+    if (int r = check_stream(c, s)) return r;
+    if (int r = c->refresh()) return r;
+    const OpvStream& st = c->mirror[s];
+    if (st.overflow) return fail(OPV_ECAPACITY, "a device log overflowed (raise opv_cfg.max_samples)");
+    HostStream& h = c->hs[s];
+    const uint32_t nf = st.n_frames < st.cap_frames ? st.n_frames : st.cap_frames;
+    if (h.popped >= nf || cap == 0) return 0;
+    const uint32_t pending = nf - h.popped;
+    std::vector<int32_t> met(pending);
+    std::vector<OpvFrameRec> rec(pending);
+    std::vector<uint8_t> fr((size_t)pending * OPV_FB);
+    HIPCHK(hipMemcpy(met.data(), st.metrics + h.popped, sizeof(int32_t) * pending, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rec.data(), st.frec + h.popped, sizeof(OpvFrameRec) * pending, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fr.data(), st.frames + (size_t)h.popped * OPV_FB, fr.size(), hipMemcpyDeviceToHost));
+    size_t w = 0;
+    uint32_t k = 0;
+    for (; k < pending && w < cap; ++k) {
+        if (met[k] == INT32_MIN) break;           // released but not decoded yet (cannot happen after opv_process)
+        if (met[k] < 0) continue;                 // dropped silent frame (ref :859, :1052)
+        if (out) std::memcpy(out + w * OPV_FB, fr.data() + (size_t)k * OPV_FB, OPV_FB);
+        if (meta) {
+            meta[w].viterbi_metric = met[k];
+            meta[w].reserved = 0;
+            meta[w].sync_quality = rec[k].quality;
+            meta[w].release_symbol = rec[k].release_sym;
+            meta[w].payload_symbol = rec[k].payload_sym;
+        }
+        ++w;
+    }
+    h.popped += k;
+    return (long)w;
+}
+
+extern "C" long opv_pop_events(opv_ctx* c, int s, opv_event* out, size_t cap) {
+    if (int r = check_stream(c, s)) return r;
+    if (int r = c->refresh()) return r;
+    const OpvStream& st = c->mirror[s];
+    HostStream& h = c->hs[s];
+    const uint32_t ne = st.n_events < st.cap_events ? st.n_events : st.cap_events;
+    if (h.events_popped >= ne || cap == 0 || !out) return 0;
+    uint32_t n = ne - h.events_popped;
+    if (n > cap) n = (uint32_t)cap;
+    static_assert(sizeof(opv_event) == sizeof(OpvEventRec), "event layouts must match");
+    HIPCHK(hipMemcpy(out, st.events + h.events_popped, sizeof(OpvEventRec) * n, hipMemcpyDeviceToHost));
+    h.events_popped += n;
+    return (long)n;
+}
+
+extern "C" int opv_get_state(opv_ctx* c, int s, opv_stream_state* out) {
+    if (int r = check_stream(c, s)) return r;
+    if (!out) return fail(OPV_EINVAL, "null out");
+    if (int r = c->refresh()) return r;
+    const OpvStream& st = c->mirror[s];
+    std::memset(out, 0, sizeof *out);
+    out->freq_offset_hz = st.freq_offset;
+    out->timing_freq = st.timing_freq;
+    out->est_offset_hz = st.est_offset;
+    out->mu = st.mu;
+    out->total_symbols = st.n_soft;
+    out->total_samples = st.total_samples;
+    out->chunk_origin = st.origin;
+    out->sync_state = st.trk_state;
+    out->frames_released = (int32_t)st.n_frames;
+    out->n_chunks = (int32_t)st.n_chunks;
+    out->flushed = st.tail_done;
+    const uint32_t nf = st.n_frames < st.cap_frames ? st.n_frames : st.cap_frames;
+    if (nf) {
+        std::vector<int32_t> met(nf);
+        HIPCHK(hipMemcpy(met.data(), st.metrics, sizeof(int32_t) * nf, hipMemcpyDeviceToHost));
+        for (int32_t m : met) {
+            if (m >= 0) { out->frames_decoded++; if (m == 0) out->frames_perfect++; }
+        }
+    }
+    return st.overflow ? fail(OPV_ECAPACITY, "a device log overflowed") : OPV_OK;
+}
+
+extern "C" int opv_device_frames(opv_ctx* c, const uint8_t** d_frames, const int32_t** d_metrics,
+                                 const int32_t** d_counts, size_t* frame_capacity) {
+    if (!c) return fail(OPV_EINVAL, "null context");
+    if (d_frames) *d_frames = c->d_frames;
+    if (d_metrics) *d_metrics = c->d_metrics;
+    if (d_counts) *d_counts = c->d_counts;
+    if (frame_capacity) *frame_capacity = c->cap_frames;
+    return OPV_OK;
+}
+
+extern "C" void* opv_hip_stream(opv_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" long opv_tap_soft(opv_ctx* c, int s, uint64_t first, double* out, size_t cap) {
+    if (int r = check_stream(c, s)) return r;
+    if (int r = c->refresh()) return r;
+    const OpvStream& st = c->mirror[s];
+    if (first >= st.n_soft || cap == 0 || !out) return 0;
+    uint64_t n = st.n_soft - first;
+    if (n > cap) n = cap;
+    HIPCHK(hipMemcpy(out, st.soft + first, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return (long)n;
+}
+
+extern "C" long opv_tap_chunks(opv_ctx* c, int s, double* out5, size_t cap) {
+    if (int r = check_stream(c, s)) return r;
+    if (int r = c->refresh()) return r;
+    const OpvStream& st = c->mirror[s];
+    uint32_t n = st.n_chunks < st.cap_chunks ? st.n_chunks : st.cap_chunks;
+    if (n > cap) n = (uint32_t)cap;
+    if (n && out5) HIPCHK(hipMemcpy(out5, st.chunk_log, sizeof(double) * 5 * n, hipMemcpyDeviceToHost));
+    return (long)n;
+}
+
+extern "C" int opv_tap_offset_energies(opv_ctx* c, int s, double* out134) {
+    if (int r = check_stream(c, s)) return r;
+    if (!out134) return fail(OPV_EINVAL, "null out");
+    if (int r = c->refresh()) return r;
+    std::memcpy(out134, c->mirror[s].energies, sizeof(double) * 134);
+    return OPV_OK;
+}
+
+extern "C" int opv_decode_payloads(opv_ctx* c, const double* soft, size_t n, uint8_t* out, int32_t* metrics,
+                                   int8_t* q, int8_t* deint, uint8_t* bits) {
+    if (!c || !soft || !out || !metrics) return fail(OPV_EINVAL, "null argument");
+    if (n == 0) return OPV_OK;
+    HIPCHK(hipSetDevice(c->cfg.device));
+    double* d_soft = nullptr;
+    uint8_t* d_out = nullptr;
+    int32_t* d_met = nullptr;
+    int8_t *d_q = nullptr, *d_d = nullptr;
+    uint8_t* d_b = nullptr;
+    int rc = OPV_OK;
+    auto chk = [&](hipError_t e, const char* w) { if (e != hipSuccess && rc == OPV_OK) rc = fail(OPV_EHIP, w, e); };
+    chk(hipMalloc(&d_soft, sizeof(double) * OPV_CODED * n), "hipMalloc soft");
+    chk(hipMalloc(&d_out, (size_t)OPV_FB * n), "hipMalloc out");
+    chk(hipMalloc(&d_met, sizeof(int32_t) * n), "hipMalloc metrics");
+    if (q) chk(hipMalloc(&d_q, (size_t)OPV_CODED * n), "hipMalloc q");
+    if (deint) chk(hipMalloc(&d_d, (size_t)OPV_CODED * n), "hipMalloc deint");
+    if (bits) chk(hipMalloc(&d_b, (size_t)OPV_FBITS * n), "hipMalloc bits");
+    if (rc == OPV_OK) {
+        chk(hipMemcpyAsync(d_soft, soft, sizeof(double) * OPV_CODED * n, hipMemcpyHostToDevice, c->stream), "H2D soft");
+        chk(hipMemsetAsync(d_out, 0, (size_t)OPV_FB * n, c->stream), "memset");
+        k_decode_payloads<<<(unsigned)n, 64, 0, c->stream>>>(d_soft, (uint32_t)n, d_out, d_met, d_q, d_d, d_b);
+        chk(hipGetLastError(), "k_decode_payloads launch");
+        chk(hipMemcpyAsync(out, d_out, (size_t)OPV_FB * n, hipMemcpyDeviceToHost, c->stream), "D2H out");
+        chk(hipMemcpyAsync(metrics, d_met, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream), "D2H metrics");
+        if (q) chk(hipMemcpyAsync(q, d_q, (size_t)OPV_CODED * n, hipMemcpyDeviceToHost, c->stream), "D2H q");
+        if (deint) chk(hipMemcpyAsync(deint, d_d, (size_t)OPV_CODED * n, hipMemcpyDeviceToHost, c->stream), "D2H deint");
+        if (bits) chk(hipMemcpyAsync(bits, d_b, (size_t)OPV_FBITS * n, hipMemcpyDeviceToHost, c->stream), "D2H bits");
+        chk(hipStreamSynchronize(c->stream), "sync");
+    }
+    void* ptrs[] = {d_soft, d_out, d_met, d_q, d_d, d_b};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    return rc;
+}
+
+extern "C" int opv_channel_device(opv_ctx* c, const int16_t* d_in, int16_t* d_out, size_t n, double gain,
+                                  double f0_hz, double sigma, uint64_t seed) {
+    if (!c || !d_in || !d_out) return fail(OPV_EINVAL, "null argument");
+    if ((n & 3u) || (((uintptr_t)d_in | (uintptr_t)d_out) & 15u))
+        return fail(OPV_EINVAL, "opv_channel_device: n must be a multiple of 4 and pointers 16-byte aligned");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const uint64_t quads = n / 4;
+    unsigned blocks = (unsigned)((quads + 255) / 256);
+    if (blocks > 256u * 8u) blocks = 256u * 8u;  // 8 blocks per CU, grid-stride the rest
+    if (blocks == 0) return OPV_OK;
+    k_channel<<<blocks, 256, 0, c->stream>>>((const int4*)d_in, (int4*)d_out, quads, gain, f0_hz / 2168000.0, sigma, seed);
+    HIPCHK(hipGetLastError());
+    return OPV_OK;
+}

@@ -1,0 +1,86 @@
+// opv_device.h — device-resident per-stream context shared by the HIP kernels and the
+// C-ABI host shim. One OpvStream per independent IQ capture; it is the "checkpoint" of
+// the carry of MSKDemodulatorAFC (reference src/opv-demod.cpp:337-347), of
+// SyncTracker (:759-780) and the chunker of main() (:1012-1076), plus device log pointers.
+#pragma once
+#include <stdint.h>
+
+#define OPV_SPS 40
+#define OPV_SYNC_BITS 24
+#define OPV_FB 134
+#define OPV_FBITS 1072
+#define OPV_CODED 2144
+#define OPV_FSYMS 2168
+#define OPV_CHUNK 86720
+#define OPV_SYNC_WORD 0x02B8DBu
+
+#define OPV_TILE_SAMPLES 2168                 // HBM->LDS staging unit: one frame tile of int16 IQ
+#define OPV_TILE_BYTES (OPV_TILE_SAMPLES * 4) // 8672 B = 542 x 16 B
+
+struct OpvFrameRec {       // written by k_sync_track, read by k_frame_decode and the host
+    uint64_t payload_sym;  // index of first payload soft symbol in the soft log
+    uint64_t release_sym;  // symbol index at which the reference releases the frame
+    double quality;        // sync_quality_
+};
+
+struct OpvEventRec {  // mirrors opv_event
+    int32_t kind;
+    int32_t count;
+    uint64_t sym_idx;
+    double corr;
+    double raw;
+};
+
+struct OpvStream {
+    // ---- inputs / logs (device pointers) ----
+    const int16_t* iq;   // sample 0 of the capture, interleaved I,Q, 16-byte aligned
+    uint64_t n_avail;    // samples available behind iq
+    int32_t eof;         // no more samples will arrive
+    int32_t pad0;
+    double* soft;        // soft-symbol log
+    uint64_t cap_soft;
+    OpvFrameRec* frec;   // frame records
+    OpvEventRec* events;
+    double* chunk_log;   // 5 doubles per demodulate() call
+    uint8_t* frames;     // [cap_frames][134]
+    int32_t* metrics;    // [cap_frames]
+    uint32_t cap_frames, cap_events, cap_chunks, pad1;
+
+    // ---- MSKDemodulatorAFC carry (ref :337-347) ----
+    double freq_offset;
+    double mu;
+    double timing_freq;
+    double afc_alpha;
+    // previous on-time correlations, stored de-rotated and pre-advanced by one symbol of LO
+    // rotation (see k_msk_frontend): P_t = S_t * exp(j 40 inc_t)
+    double p1r, p1i, p2r, p2i;
+    double fo_sum;            // sum of the freq_offset used by every symbol so far (absolute LO phase, see k_frontend)
+    double est_offset;        // NaN until estimate_offset ran
+    double energies[134];     // offset-search tap
+
+    // ---- chunker carry (ref :1012-1076) ----
+    uint64_t origin;          // sample index where the next demodulate() call starts
+    uint64_t total_samples;   // sum of chunk sizes processed (ref :1027)
+    uint64_t n_soft;          // symbols produced so far
+    uint32_t n_chunks;
+    int32_t first_chunk_done; // offset search done or skipped
+    int32_t tail_done;        // EOF tail processed
+    int32_t overflow;         // a log ran out of capacity
+
+    // ---- SyncTracker carry (ref :759-780), expressed on soft-log positions ----
+    int32_t trk_state;        // OPV_HUNTING / VERIFYING / LOCKED
+    int32_t trk_collecting;   // a payload is pending release at anchor+2144
+    uint64_t trk_anchor;      // symbol at which symbols_since_sync_ was last reset
+    uint64_t trk_next;        // next symbol index the tracker has not consumed yet
+    double trk_quality;
+    int32_t trk_misses;
+    uint32_t n_frames;        // frames released (total_frames_)
+    uint32_t n_events;
+    uint32_t dec_from;        // first frame record k_frame_decode must handle this round
+};
+
+struct OpvGlobalCfg {
+    int32_t streaming;
+    int32_t have_init_offset;
+    double init_offset;
+};

@@ -1,0 +1,170 @@
+// opv_tx.cpp — host-side OPV transmit chain (signal source for tests, the CLI and the bench).
+//
+// Behaviourally identical, bit for bit, to the reference modulator program
+// (reference src/opv-mod.cpp; behaviour spec in SURVEY.md Appendix A): BERT frame builder
+// (:339-361), CCSDS randomiser (:97-113), K=7 r=1/2 encoder (:120-136, last byte first, MSB
+// first :186-196), 67x32 interleaver with in-byte bit reversal (:142-153), sync word MSB
+// first (:315-321) and the parallel-tone MSK modulator (:219-291) followed by 100 zero
+// symbols (:528-529). Pinned by sha256 against `opv-mod` output (tests/test_host_tx.py).
+//
+// Design (not the reference's): the per-symbol tone/sign sequence and the NCO phases at each
+// frame boundary are produced by one cheap sequential pass (the NCOs free-run with the
+// reference's repeated-addition + wrap arithmetic, so the values are reproduced exactly);
+// the expensive part — one libm sin/cos pair per sample for the ACTIVE tone only, the other
+// tone contributes an exact +/-0 — then runs frame-parallel on host threads.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/opv_demod.h"
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;  // opv-mod.cpp:43
+constexpr double kTwoPi = 2.0 * kPi;
+constexpr double kFs = 2168000.0;
+constexpr double kDev = 54200.0 / 4.0;  // opv-mod.cpp:36-37
+constexpr uint32_t kSync = 0x02B8DB;
+constexpr int kSps = OPV_SAMPLES_PER_SYMBOL;
+
+struct LfsrBytes {
+    uint8_t b[OPV_FRAME_BYTES];
+    LfsrBytes() {
+        unsigned st = 0xFF;
+        for (auto& o : b) {
+            unsigned v = 0;
+            for (int k = 0; k < 8; ++k) {
+                v = (v << 1) | ((st >> 7) & 1u);
+                st = ((st << 1) | (((st >> 7) ^ (st >> 6) ^ (st >> 4) ^ (st >> 2)) & 1u)) & 0xFFu;
+            }
+            o = (uint8_t)v;
+        }
+    }
+};
+const LfsrBytes kLfsr;
+
+inline size_t interleave_pos(size_t i) {  // opv-mod.cpp:145-149
+    const size_t p = (i % 32) * 67 + i / 32;
+    return (p & ~size_t(7)) | (7 - (p & 7));
+}
+
+// 24 sync bits + 2144 interleaved coded bits of one frame, in on-air order
+void frame_symbols(const uint8_t* payload, uint8_t* sym /*2168*/) {
+    for (int b = 0; b < 24; ++b) sym[b] = (kSync >> (23 - b)) & 1u;
+    uint8_t* coded = sym + 24;
+    unsigned sr = 0;
+    size_t o = 0;
+    for (int byte = OPV_FRAME_BYTES - 1; byte >= 0; --byte) {
+        const unsigned v = payload[byte] ^ kLfsr.b[byte];
+        for (int bit = 7; bit >= 0; --bit) {
+            const unsigned in = (v >> bit) & 1u;
+            const unsigned reg = (in << 6) | sr;
+            coded[interleave_pos(o++)] = (uint8_t)__builtin_parity(reg & 0x4F);
+            coded[interleave_pos(o++)] = (uint8_t)__builtin_parity(reg & 0x6D);
+            sr = ((sr << 1) | in) & 0x3F;
+        }
+    }
+}
+
+inline void advance(double& ph, double inc) {  // opv-mod.cpp:274-279
+    ph += inc;
+    while (ph > kPi) ph -= kTwoPi;
+    while (ph < -kPi) ph += kTwoPi;
+}
+
+struct FrameStart {
+    double ph1, ph2;
+};
+
+}  // namespace
+
+extern "C" void opv_tx_bert_frame(const char* callsign, uint32_t token, uint32_t frame_num,
+                                  uint8_t out[OPV_FRAME_BYTES]) {
+    std::memset(out, 0, OPV_FRAME_BYTES);
+    size_t len = std::strlen(callsign);
+    if (len > 9) len = 9;  // opv-mod.cpp:451-454
+    uint64_t v = 0;
+    for (size_t k = len; k-- > 0;) {  // first character least significant (opv-mod.cpp:66-70)
+        const char c = callsign[k];
+        unsigned d = 0;
+        if (c >= 'A' && c <= 'Z') d = c - 'A' + 1;
+        else if (c >= 'a' && c <= 'z') d = c - 'a' + 1;
+        else if (c >= '0' && c <= '9') d = c - '0' + 27;
+        else if (c == '-') d = 37;
+        else if (c == '/') d = 38;
+        else if (c == '.') d = 39;
+        v = v * 40 + d;
+    }
+    for (int b = 0; b < 6; ++b) out[b] = (uint8_t)(v >> (40 - 8 * b));
+    out[6] = (uint8_t)(token >> 16);
+    out[7] = (uint8_t)(token >> 8);
+    out[8] = (uint8_t)token;
+    for (unsigned i = 0; i < OPV_FRAME_BYTES - 12; ++i) out[12 + i] = (uint8_t)(frame_num + i);
+}
+
+extern "C" size_t opv_tx_modulated_samples(size_t n_frames) {
+    return n_frames * (size_t)OPV_FRAME_SYMBOLS * kSps + 100u * kSps;
+}
+
+extern "C" size_t opv_tx_modulate(const uint8_t* frames, size_t n_frames, int16_t* iq) {
+    const size_t nsym = n_frames * OPV_FRAME_SYMBOLS;
+    // pass 1 (sequential, cheap): per-symbol active tone + sign, NCO phases at frame starts
+    std::vector<int8_t> amp(nsym);  // +/-1: tone 1 active with that sign; +/-2: tone 2; 0: silent
+    std::vector<FrameStart> fs(n_frames);
+    {
+        std::vector<uint8_t> sym(OPV_FRAME_SYMBOLS);
+        int T = 0, bn = 1;  // opv-mod.cpp:221-226
+        double ph1 = 0.0, ph2 = 0.0;
+        const double inc1 = kTwoPi * (-kDev) / kFs, inc2 = kTwoPi * (+kDev) / kFs;
+        for (size_t f = 0; f < n_frames; ++f) {
+            fs[f] = {ph1, ph2};
+            frame_symbols(frames + f * OPV_FRAME_BYTES, sym.data());
+            for (int k = 0; k < OPV_FRAME_SYMBOLS; ++k) {
+                const int d = sym[k] ? -1 : 1;
+                int a;
+                if (d == 1) a = T;                                  // tone 1, sign T (0 right after reset)
+                else a = 2 * ((bn == 0) ? -T : T);                  // tone 2, sign +/-T by symbol parity
+                amp[f * OPV_FRAME_SYMBOLS + k] = (int8_t)a;
+                T = (T == 0) ? 1 : d * T;
+                bn ^= 1;
+            }
+            for (int k = 0; k < OPV_FRAME_SYMBOLS * kSps; ++k) { advance(ph1, inc1); advance(ph2, inc2); }
+        }
+    }
+    // pass 2 (frame-parallel): samples
+    auto work = [&](size_t f0, size_t f1) {
+        const double inc1 = kTwoPi * (-kDev) / kFs, inc2 = kTwoPi * (+kDev) / kFs;
+        for (size_t f = f0; f < f1; ++f) {
+            double ph1 = fs[f].ph1, ph2 = fs[f].ph2;
+            int16_t* o = iq + f * (size_t)OPV_FRAME_SYMBOLS * kSps * 2;
+            for (int k = 0; k < OPV_FRAME_SYMBOLS; ++k) {
+                const int a = amp[f * OPV_FRAME_SYMBOLS + k];
+                for (int i = 0; i < kSps; ++i) {
+                    double I = 0.0, Q = 0.0;
+                    if (a == 1 || a == -1) { I = a * std::sin(ph1); Q = a * std::cos(ph1); }
+                    else if (a == 2 || a == -2) { const int s = a / 2; I = s * std::sin(ph2); Q = s * std::cos(ph2); }
+                    *o++ = (int16_t)(16383.0 * I);  // truncation toward zero (opv-mod.cpp:271-272)
+                    *o++ = (int16_t)(16383.0 * Q);
+                    advance(ph1, inc1);
+                    advance(ph2, inc2);
+                }
+            }
+        }
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 16) nt = 16;
+    if (nt > n_frames) nt = (unsigned)(n_frames ? n_frames : 1);
+    std::vector<std::thread> pool;
+    const size_t per = (n_frames + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t a = t * per, b = (a + per < n_frames) ? a + per : n_frames;
+        if (a < b) pool.emplace_back(work, a, b);
+    }
+    for (auto& th : pool) th.join();
+    const size_t body = nsym * kSps;
+    std::memset(iq + 2 * body, 0, sizeof(int16_t) * 2u * 100u * kSps);
+    return body + 100u * kSps;
+}

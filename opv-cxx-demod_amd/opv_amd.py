@@ -1,0 +1,276 @@
+"""ctypes binding of the C ABI in include/opv_demod.h (libopv_demod_hip.so).
+
+Python is plumbing here (tests, bench, multi-GPU launch); the product is the shared library.
+The directory name of this package contains a '-', so import it by path:
+
+    import importlib.util, pathlib
+    spec = importlib.util.spec_from_file_location("opv_amd", ".../opv-cxx-demod_amd/opv_amd.py")
+
+or use ``load_opv_amd()`` from the repo-root ``__graft_entry__``.
+There is no CPU fallback: if the library is missing or no MI355X is visible, calls raise.
+"""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libopv_demod_hip.so"
+
+SPS = 40
+FRAME_BYTES = 134
+FRAME_BITS = 1072
+ENCODED_BITS = 2144
+FRAME_SYMBOLS = 2168
+CHUNK_SAMPLES = 86720
+SAMPLE_RATE = 2168000.0
+
+EXPORTS = [
+    "opv_create", "opv_destroy", "opv_last_error", "opv_abi_version", "opv_push_iq", "opv_flush",
+    "opv_attach_device_iq", "opv_process", "opv_sync", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
+    "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_tap_soft", "opv_tap_chunks",
+    "opv_tap_offset_energies", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_modulated_samples",
+    "opv_tx_modulate", "opv_channel_device",
+]
+
+
+class OpvError(RuntimeError):
+    pass
+
+
+class Cfg(C.Structure):
+    _fields_ = [("streaming", C.c_int32), ("have_init_offset", C.c_int32), ("init_offset_hz", C.c_double),
+                ("afc_alpha", C.c_double), ("device", C.c_int32), ("keep_soft", C.c_int32),
+                ("max_samples", C.c_uint64)]
+
+
+class FrameMeta(C.Structure):
+    _fields_ = [("viterbi_metric", C.c_int32), ("reserved", C.c_int32), ("sync_quality", C.c_double),
+                ("release_symbol", C.c_uint64), ("payload_symbol", C.c_uint64)]
+
+
+class StreamState(C.Structure):
+    _fields_ = [("freq_offset_hz", C.c_double), ("timing_freq", C.c_double), ("est_offset_hz", C.c_double),
+                ("mu", C.c_double), ("total_symbols", C.c_uint64), ("total_samples", C.c_uint64),
+                ("chunk_origin", C.c_uint64), ("sync_state", C.c_int32), ("frames_released", C.c_int32),
+                ("frames_decoded", C.c_int32), ("frames_perfect", C.c_int32), ("n_chunks", C.c_int32),
+                ("flushed", C.c_int32)]
+
+
+EVENT_DTYPE = np.dtype(
+    [("kind", "<i4"), ("count", "<i4"), ("sym_idx", "<u8"), ("corr", "<f8"), ("raw", "<f8")], align=True)
+META_DTYPE = np.dtype([("viterbi_metric", "<i4"), ("reserved", "<i4"), ("sync_quality", "<f8"),
+                       ("release_symbol", "<u8"), ("payload_symbol", "<u8")], align=True)
+
+
+def build(force=False):
+    """Compile the library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not LIB_PATH.exists():
+        subprocess.run(["make", "-s", "-C", str(PKG), "-j8", "all"], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise OpvError(f"{LIB_PATH} is missing: run `make -C {PKG}` (there is no CPU fallback)")
+        L = C.CDLL(str(LIB_PATH))
+        L.opv_last_error.restype = C.c_char_p
+        L.opv_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Cfg)]
+        L.opv_destroy.argtypes = [C.c_void_p]
+        L.opv_destroy.restype = None
+        L.opv_push_iq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.opv_flush.argtypes = [C.c_void_p, C.c_int]
+        L.opv_attach_device_iq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
+        L.opv_process.argtypes = [C.c_void_p]
+        L.opv_sync.argtypes = [C.c_void_p]
+        L.opv_reset_stream.argtypes = [C.c_void_p, C.c_int]
+        L.opv_pop_frames.restype = C.c_long
+        L.opv_pop_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.opv_pop_events.restype = C.c_long
+        L.opv_pop_events.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.opv_get_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(StreamState)]
+        L.opv_device_frames.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.opv_hip_stream.restype = C.c_void_p
+        L.opv_hip_stream.argtypes = [C.c_void_p]
+        L.opv_tap_soft.restype = C.c_long
+        L.opv_tap_soft.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_size_t]
+        L.opv_tap_chunks.restype = C.c_long
+        L.opv_tap_chunks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.opv_tap_offset_energies.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.opv_decode_payloads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.opv_tx_bert_frame.restype = None
+        L.opv_tx_bert_frame.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.opv_tx_modulated_samples.restype = C.c_size_t
+        L.opv_tx_modulated_samples.argtypes = [C.c_size_t]
+        L.opv_tx_modulate.restype = C.c_size_t
+        L.opv_tx_modulate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.opv_channel_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double,
+                                         C.c_double, C.c_uint64]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc < 0:
+        raise OpvError(f"opv error {rc}: {lib().opv_last_error().decode()}")
+    return rc
+
+
+# ---------------------------------------------------------------- transmit side (host)
+def bert_frames(n, callsign="W5NYV", token=0xBBAADD, first=0):
+    out = np.zeros((n, FRAME_BYTES), np.uint8)
+    for k in range(n):
+        lib().opv_tx_bert_frame(callsign.encode(), token, first + k, out[k].ctypes.data)
+    return out
+
+
+def modulate(frames):
+    frames = np.ascontiguousarray(frames, np.uint8).reshape(-1, FRAME_BYTES)
+    n = lib().opv_tx_modulated_samples(len(frames))
+    iq = np.empty(2 * n, np.int16)
+    w = lib().opv_tx_modulate(frames.ctypes.data, len(frames), iq.ctypes.data)
+    assert w == n
+    return iq
+
+
+# ---------------------------------------------------------------- receiver
+class Demod:
+    """n_streams independent receivers on one GPU (mirrors the three reference objects
+    MSKDemodulatorAFC + SyncTracker + FrameDecoder per stream)."""
+
+    def __init__(self, n_streams=1, max_samples=1 << 22, streaming=True, init_offset=None, afc_alpha=0.001,
+                 device=0):
+        self.n_streams = n_streams
+        self.cfg = Cfg(int(streaming), int(init_offset is not None), float(init_offset or 0.0), afc_alpha,
+                       device, 1, int(max_samples))
+        self.h = C.c_void_p()
+        _chk(lib().opv_create(C.byref(self.h), n_streams, C.byref(self.cfg)))
+
+    def close(self):
+        if self.h:
+            lib().opv_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def push(self, stream, iq):
+        iq = np.ascontiguousarray(iq, np.int16).reshape(-1)
+        _chk(lib().opv_push_iq(self.h, stream, iq.ctypes.data, iq.size // 2))
+
+    def flush(self, stream):
+        _chk(lib().opv_flush(self.h, stream))
+
+    def attach(self, stream, dev_ptr, n_samples, eof=True):
+        _chk(lib().opv_attach_device_iq(self.h, stream, C.c_void_p(dev_ptr), n_samples, int(eof)))
+
+    def process(self):
+        _chk(lib().opv_process(self.h))
+
+    def sync(self):
+        _chk(lib().opv_sync(self.h))
+
+    def reset(self, stream):
+        _chk(lib().opv_reset_stream(self.h, stream))
+
+    def pop_frames(self, stream, cap=None):
+        cap = cap or (int(self.cfg.max_samples) // (FRAME_SYMBOLS * 38) + 8)
+        out = np.zeros((cap, FRAME_BYTES), np.uint8)
+        meta = np.zeros(cap, META_DTYPE)
+        n = _chk(lib().opv_pop_frames(self.h, stream, out.ctypes.data, cap, meta.ctypes.data))
+        return out[:n].copy(), meta[:n].copy()
+
+    def pop_events(self, stream, cap=None):
+        cap = cap or (4 * (int(self.cfg.max_samples) // (FRAME_SYMBOLS * 38) + 8) + 64)
+        ev = np.zeros(cap, EVENT_DTYPE)
+        n = _chk(lib().opv_pop_events(self.h, stream, ev.ctypes.data, cap))
+        return ev[:n].copy()
+
+    def state(self, stream):
+        s = StreamState()
+        _chk(lib().opv_get_state(self.h, stream, C.byref(s)))
+        return s
+
+    def soft(self, stream, first=0, cap=None):
+        cap = cap or (int(self.cfg.max_samples) // 38 + 128)
+        out = np.empty(cap, np.float64)
+        n = _chk(lib().opv_tap_soft(self.h, stream, first, out.ctypes.data, cap))
+        return out[:n].copy()
+
+    def chunks(self, stream):
+        cap = int(self.cfg.max_samples) // 80000 + 4
+        out = np.zeros((cap, 5), np.float64)
+        n = _chk(lib().opv_tap_chunks(self.h, stream, out.ctypes.data, cap))
+        return out[:n].copy()
+
+    def offset_energies(self, stream):
+        out = np.zeros(134, np.float64)
+        _chk(lib().opv_tap_offset_energies(self.h, stream, out.ctypes.data))
+        return out
+
+    def decode_payloads(self, soft, taps=False):
+        soft = np.ascontiguousarray(soft, np.float64).reshape(-1, ENCODED_BITS)
+        n = len(soft)
+        out = np.zeros((n, FRAME_BYTES), np.uint8)
+        met = np.zeros(n, np.int32)
+        q = np.zeros((n, ENCODED_BITS), np.int8) if taps else None
+        de = np.zeros((n, ENCODED_BITS), np.int8) if taps else None
+        bits = np.zeros((n, FRAME_BITS), np.uint8) if taps else None
+        _chk(lib().opv_decode_payloads(self.h, soft.ctypes.data, n, out.ctypes.data, met.ctypes.data,
+                                       q.ctypes.data if taps else None, de.ctypes.data if taps else None,
+                                       bits.ctypes.data if taps else None))
+        return dict(frames=out, metrics=met, q=q, deint=de, bits=bits)
+
+    def device_frames(self):
+        f, m, c, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_size_t()
+        _chk(lib().opv_device_frames(self.h, C.byref(f), C.byref(m), C.byref(c), C.byref(cap)))
+        return f.value, m.value, c.value, cap.value
+
+    def hip_stream(self):
+        return lib().opv_hip_stream(self.h)
+
+    def channel(self, d_in, d_out, n_samples, gain=1.0, f0_hz=0.0, sigma=0.0, seed=0):
+        _chk(lib().opv_channel_device(self.h, C.c_void_p(d_in), C.c_void_p(d_out), n_samples, gain, f0_hz, sigma,
+                                      seed))
+
+    # convenience: the whole reference main() for one host capture on stream 0..n-1
+    def receive(self, captures):
+        """captures: list of int16 IQ arrays, one per stream. Returns per-stream dicts."""
+        assert len(captures) == self.n_streams
+        for s, iq in enumerate(captures):
+            self.push(s, iq)
+            self.flush(s)
+        self.process()
+        self.sync()
+        res = []
+        for s in range(self.n_streams):
+            fr, meta = self.pop_frames(s)
+            st = self.state(s)
+            res.append(dict(frames=fr, meta=meta, events=self.pop_events(s), soft=self.soft(s), state=st,
+                            chunks=self.chunks(s)))
+        return res
+
+
+def format_events(events):
+    """The stderr lines of SyncTracker::process (reference src/opv-demod.cpp:651,677,695,699,705)."""
+    lines = []
+    for e in events:
+        k, idx = int(e["kind"]), int(e["sym_idx"])
+        if k == 1:
+            lines.append("[%d] HUNTING→VERIFYING (corr=%.3f, raw=%.0f)" % (idx, e["corr"], e["raw"]))
+        elif k == 2:
+            lines.append("[%d] VERIFYING→LOCKED (frame %d)" % (idx, e["count"]))
+        elif k == 3:
+            lines.append("[%d] LOCKED: sync OK (corr=%.3f)" % (idx, e["corr"]))
+        elif k == 4:
+            lines.append("[%d] LOCKED: sync MISS #%d (corr=%.3f)" % (idx, e["count"], e["corr"]))
+        elif k == 5:
+            lines.append("[%d] LOCKED→HUNTING (lost lock)" % idx)
+    return lines
