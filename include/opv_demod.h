@@ -129,8 +129,15 @@ int opv_attach_device_iq(opv_ctx* ctx, int stream, const int16_t* d_iq, size_t n
  * decode (FrameDecoder::decode :854-898). Asynchronous; opv_sync waits. */
 int opv_process(opv_ctx* ctx);
 int opv_sync(opv_ctx* ctx);
-/* Restores a stream to its freshly-created state (keeps buffers). */
+/* Restores a stream (stream = -1: every stream) to its freshly-created state (keeps buffers). */
 int opv_reset_stream(opv_ctx* ctx, int stream);
+
+/* Measurement hook: when enabled, opv_process brackets each of its four hot-path kernels
+ * with HIP events on the context's stream. opv_kernel_times (implies opv_sync) returns the
+ * durations in milliseconds of the LAST opv_process: [0] offset search, [1] MSK front-end,
+ * [2] sync tracker, [3] frame decode. */
+int opv_enable_timing(opv_ctx* ctx, int enable);
+int opv_kernel_times(opv_ctx* ctx, float ms_out[4]);
 
 /* ---- results --------------------------------------------------------------------------
  * opv_pop_frames replaces the frame writer (src/opv-demod.cpp:1052-1062): frames whose

@@ -104,6 +104,9 @@ struct opv_ctx {
     uint64_t cap_soft = 0;
     uint32_t cap_frames = 0, cap_events = 0, cap_chunks = 0;
     bool mirror_valid = false;
+    bool timing = false;
+    bool timing_valid = false;
+    hipEvent_t ev[8] = {};
 
     int refresh() {
         if (mirror_valid) return OPV_OK;
@@ -198,6 +201,8 @@ extern "C" void opv_destroy(opv_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& h : c->hs)
         if (h.d_iq_owned) (void)hipFree(h.d_iq_owned);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
     void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_counts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -279,13 +284,19 @@ extern "C" int opv_process(opv_ctx* c) {
     HIPCHK(hipStreamSynchronize(c->stream));
     OpvGlobalCfg g{c->cfg.streaming, c->cfg.have_init_offset, c->cfg.init_offset_hz};
     k_apply_inputs<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_in, S);
+    const bool tm = c->timing;
+    if (tm) HIPCHK(hipEventRecord(c->ev[0], c->stream));
     k_offset_search<<<S, 256, 0, c->stream>>>(c->d_streams, g);
+    if (tm) { HIPCHK(hipEventRecord(c->ev[1], c->stream)); HIPCHK(hipEventRecord(c->ev[2], c->stream)); }
     k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g);
+    if (tm) { HIPCHK(hipEventRecord(c->ev[3], c->stream)); HIPCHK(hipEventRecord(c->ev[4], c->stream)); }
     k_sync_track<<<S, 64, 0, c->stream>>>(c->d_streams);
+    if (tm) { HIPCHK(hipEventRecord(c->ev[5], c->stream)); HIPCHK(hipEventRecord(c->ev[6], c->stream)); }
     // frames a stream can release this round: new symbols / 2168 plus what was pending
     uint64_t fr = max_new / (uint64_t)(OPV_FSYMS * 38) + 4;
     if (fr > c->cap_frames) fr = c->cap_frames;
     k_frame_decode<<<dim3((unsigned)fr, (unsigned)S), 64, 0, c->stream>>>(c->d_streams);
+    if (tm) { HIPCHK(hipEventRecord(c->ev[7], c->stream)); c->timing_valid = true; }
     k_collect_counts<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_counts, S);
     HIPCHK(hipGetLastError());
     return OPV_OK;
@@ -298,19 +309,44 @@ extern "C" int opv_sync(opv_ctx* c) {
 }
 
 extern "C" int opv_reset_stream(opv_ctx* c, int s) {
-    if (int r = check_stream(c, s)) return r;
+    if (!c) return fail(OPV_EINVAL, "null context");
+    if (s != -1) { if (int r = check_stream(c, s)) return r; }
+    HIPCHK(hipSetDevice(c->cfg.device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HostStream& h = c->hs[s];
-    int16_t* keep = h.d_iq_owned;
-    size_t cap = h.iq_cap;
-    h = HostStream();
-    h.d_iq_owned = keep;
-    h.iq_cap = cap;
-    h.d_iq = keep;
-    HIPCHK(hipMemcpy(c->d_streams + s, &c->initial[s], sizeof(OpvStream), hipMemcpyHostToDevice));
-    k_fill_i32<<<64, 256, 0, c->stream>>>(c->d_metrics + (size_t)c->cap_frames * s, INT32_MIN, c->cap_frames);
+    const int lo = (s == -1) ? 0 : s, hi = (s == -1) ? c->n_streams : s + 1;
+    for (int i = lo; i < hi; ++i) {
+        HostStream& h = c->hs[i];
+        int16_t* keep = h.d_iq_owned;
+        const size_t cap = h.iq_cap;
+        h = HostStream();
+        h.d_iq_owned = keep;
+        h.iq_cap = cap;
+        h.d_iq = keep;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_streams + lo, &c->initial[lo], sizeof(OpvStream) * (hi - lo), hipMemcpyHostToDevice, c->stream));
+    k_fill_i32<<<256, 256, 0, c->stream>>>(c->d_metrics + (size_t)c->cap_frames * lo, INT32_MIN,
+                                          (size_t)c->cap_frames * (hi - lo));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->mirror_valid = false;
+    return OPV_OK;
+}
+
+extern "C" int opv_enable_timing(opv_ctx* c, int enable) {
+    if (!c) return fail(OPV_EINVAL, "null context");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (enable)
+        for (auto& e : c->ev)
+            if (!e) HIPCHK(hipEventCreate(&e));
+    c->timing = enable != 0;
+    c->timing_valid = false;
+    return OPV_OK;
+}
+
+extern "C" int opv_kernel_times(opv_ctx* c, float ms[4]) {
+    if (!c || !ms) return fail(OPV_EINVAL, "null argument");
+    if (!c->timing_valid) return fail(OPV_ESTATE, "no timed opv_process yet (opv_enable_timing first)");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 4; ++k) HIPCHK(hipEventElapsedTime(&ms[k], c->ev[2 * k], c->ev[2 * k + 1]));
     return OPV_OK;
 }
 

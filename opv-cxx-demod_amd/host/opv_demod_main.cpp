@@ -1,0 +1,315 @@
+// opv_demod_main.cpp — host program with the process contract of the reference `opv-demod`
+// (reference src/opv-demod.cpp:943-1217): int16 I/Q on stdin, 134-byte frames on stdout
+// (-r), human text on stderr, flags -q -r -s -a -o -h (-c/-p: coherent mode, out of scope),
+// exit status 0 iff at least one frame decoded. All arithmetic runs on the MI355X through
+// the C ABI in include/opv_demod.h; this file only moves bytes and prints.
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/opv_demod.h"
+
+namespace {
+
+constexpr double kFs = 2168000.0;
+
+// Base-40 station id (ref :87-103): first character least significant
+std::string base40(const uint8_t* b) {
+    uint64_t v = 0;
+    for (int i = 0; i < 6; ++i) v = (v << 8) | b[i];
+    if (v == 0) return "(empty)";
+    std::string s;
+    while (v > 0) {
+        const int d = (int)(v % 40);
+        v /= 40;
+        char c = 0;
+        if (d >= 1 && d <= 26) c = (char)('A' + d - 1);
+        else if (d >= 27 && d <= 36) c = (char)('0' + d - 27);
+        else if (d == 37) c = '-';
+        else if (d == 38) c = '/';
+        else if (d == 39) c = '.';
+        if (c) s += c;
+    }
+    return s.empty() ? "(empty)" : s;
+}
+
+const char* state_name(int s) {  // ref :75-82
+    return s == OPV_HUNTING ? "HUNTING" : s == OPV_VERIFYING ? "VERIFYING" : s == OPV_LOCKED ? "LOCKED" : "?";
+}
+
+void print_event(const opv_event& e) {  // ref :651,677,695,699,705
+    const unsigned long long i = e.sym_idx;
+    switch (e.kind) {
+        case OPV_EV_HUNT_TO_VERIFY: fprintf(stderr, "[%llu] HUNTING→VERIFYING (corr=%.3f, raw=%.0f)\n", i, e.corr, e.raw); break;
+        case OPV_EV_VERIFY_TO_LOCK: fprintf(stderr, "[%llu] VERIFYING→LOCKED (frame %d)\n", i, e.count); break;
+        case OPV_EV_SYNC_OK: fprintf(stderr, "[%llu] LOCKED: sync OK (corr=%.3f)\n", i, e.corr); break;
+        case OPV_EV_SYNC_MISS: fprintf(stderr, "[%llu] LOCKED: sync MISS #%d (corr=%.3f)\n", i, e.count, e.corr); break;
+        case OPV_EV_LOST_LOCK: fprintf(stderr, "[%llu] LOCKED→HUNTING (lost lock)\n", i); break;
+        default: break;
+    }
+}
+
+void print_frame(int num, const uint8_t* f, int metric, double sync) {  // ref :907-938
+    fprintf(stderr, "┌─────────────────────────────────────────────────────────────────┐\n");
+    fprintf(stderr, "│ FRAME %4d  │  Sync: %.3f  │  Metric: %5d", num, sync, metric);
+    if (metric == 0) fprintf(stderr, " (perfect)");
+    fprintf(stderr, "\n├─────────────────────────────────────────────────────────────────┤\n");
+    fprintf(stderr, "│ Station ID:  %-12s (Base-40)\n", base40(f).c_str());
+    const uint32_t tok = ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 8) | f[8];
+    fprintf(stderr, "│ Token:       0x%06X%s\n", tok, tok == 0xBBAADD ? " (default)" : "");
+    const uint32_t res = ((uint32_t)f[9] << 16) | ((uint32_t)f[10] << 8) | f[11];
+    fprintf(stderr, "│ Reserved:    0x%06X\n", res);
+    fprintf(stderr, "├─────────────────────────────────────────────────────────────────┤\n");
+    fprintf(stderr, "│ Hex Dump:                                                       │\n");
+    for (size_t i = 0; i < OPV_FRAME_BYTES; i += 16) {
+        fprintf(stderr, "│ %02zx: ", i);
+        for (size_t j = i; j < i + 16 && j < OPV_FRAME_BYTES; ++j) fprintf(stderr, "%02X ", f[j]);
+        for (size_t j = OPV_FRAME_BYTES; j < i + 16; ++j) fprintf(stderr, "   ");
+        fprintf(stderr, " │");
+        for (size_t j = i; j < i + 16 && j < OPV_FRAME_BYTES; ++j) fprintf(stderr, "%c", (f[j] >= 0x20 && f[j] < 0x7F) ? f[j] : '.');
+        fprintf(stderr, "│\n");
+    }
+    fprintf(stderr, "└─────────────────────────────────────────────────────────────────┘\n\n");
+}
+
+struct Options {
+    bool quiet = false, raw = false, coherent = false, streaming = false, have_off = false;
+    double afc = 0.001, off = 0.0, capacity_sec = 120.0;
+    int device = 0;
+};
+
+struct Sink {
+    opv_ctx* ctx;
+    Options o;
+    int decoded = 0, perfect = 0;
+    size_t chunks_seen = 0;
+    uint64_t total_samples = 0, total_symbols = 0;
+    uint64_t full_samples = 0, full_symbols = 0;  // what the reference's Total: line counts (full chunks only, ref :1027,:1067)
+    bool est_printed = false;
+
+    void write_frame(const uint8_t* f) {
+        // one write(2) per frame, like the 134-byte fully-buffered stdout of the reference (ref :978-979)
+        size_t off = 0;
+        while (off < OPV_FRAME_BYTES) {
+            ssize_t w = ::write(STDOUT_FILENO, f + off, OPV_FRAME_BYTES - off);
+            if (w <= 0) return;
+            off += (size_t)w;
+        }
+    }
+
+    // Print everything the device produced since the last call, in the order the reference
+    // would have printed it: per chunk, tracker lines and frames by symbol index, then the
+    // 5-second status line (ref :1045-1083).
+    int drain() {
+        opv_stream_state st;
+        if (opv_get_state(ctx, 0, &st) < 0) return -1;
+        if (!o.quiet && o.streaming && !est_printed && !std::isnan(st.est_offset_hz)) {
+            fprintf(stderr, "Estimated carrier offset: %.1f Hz\n\n", st.est_offset_hz);  // ref :1035
+            est_printed = true;
+        }
+        std::vector<opv_event> ev(4096);
+        std::vector<uint8_t> fr(256 * OPV_FRAME_BYTES);
+        std::vector<opv_frame_meta> meta(256);
+        std::vector<opv_event> all_ev;
+        std::vector<uint8_t> all_fr;
+        std::vector<opv_frame_meta> all_meta;
+        for (;;) {
+            long n = opv_pop_events(ctx, 0, ev.data(), ev.size());
+            if (n < 0) return -1;
+            all_ev.insert(all_ev.end(), ev.begin(), ev.begin() + n);
+            if ((size_t)n < ev.size()) break;
+        }
+        for (;;) {
+            long n = opv_pop_frames(ctx, 0, fr.data(), 256, meta.data());
+            if (n < 0) return -1;
+            all_fr.insert(all_fr.end(), fr.begin(), fr.begin() + n * OPV_FRAME_BYTES);
+            all_meta.insert(all_meta.end(), meta.begin(), meta.begin() + n);
+            if (n < 256) break;
+        }
+        std::vector<double> cl((size_t)st.n_chunks * 5);
+        if (st.n_chunks && opv_tap_chunks(ctx, 0, cl.data(), st.n_chunks) < 0) return -1;
+
+        size_t ie = 0, ifr = 0;
+        auto emit_until = [&](uint64_t sym_end) {  // everything with symbol index < sym_end
+            for (;;) {
+                const bool he = ie < all_ev.size() && all_ev[ie].sym_idx < sym_end;
+                const bool hf = ifr < all_meta.size() && all_meta[ifr].release_symbol < sym_end;
+                if (!he && !hf) break;
+                if (he && (!hf || all_ev[ie].sym_idx <= all_meta[ifr].release_symbol)) {
+                    print_event(all_ev[ie++]);  // tracker lines are printed even under -q (ref :651)
+                } else {
+                    const opv_frame_meta& m = all_meta[ifr];
+                    const uint8_t* f = all_fr.data() + ifr * OPV_FRAME_BYTES;
+                    ++decoded;
+                    if (m.viterbi_metric == 0) ++perfect;
+                    if (!o.quiet) print_frame(decoded, f, m.viterbi_metric, m.sync_quality);
+                    if (o.raw) write_frame(f);
+                    ++ifr;
+                }
+            }
+        };
+        for (; chunks_seen < (size_t)st.n_chunks; ++chunks_seen) {
+            const double* c = &cl[chunks_seen * 5];
+            const uint64_t nsym = (uint64_t)c[4];
+            // chunk size = what demodulate() was given: full chunks are 86720, the tail is the rest
+            emit_until(total_symbols + nsym);
+            total_symbols += nsym;
+            if (o.streaming) {
+                const bool tail = st.flushed && chunks_seen + 1 == (size_t)st.n_chunks && (uint64_t)st.total_samples - total_samples < OPV_CHUNK_SAMPLES;
+                const uint64_t csz = tail ? (uint64_t)st.total_samples - total_samples : OPV_CHUNK_SAMPLES;
+                total_samples += csz;
+                if (!tail) { full_samples += csz; full_symbols += nsym; }
+                if (!tail && !o.quiet && (total_samples % (uint64_t)(kFs * 5) < OPV_CHUNK_SAMPLES))  // ref :1079-1083
+                    fprintf(stderr, "[%.1fs] %llu symbols, %d frames (%d perfect), AFC: %.1f Hz, TFreq: %.4f\n",
+                            total_samples / kFs, (unsigned long long)total_symbols, decoded, perfect, c[0], c[1]);
+            }
+        }
+        emit_until(~0ull);
+        return 0;
+    }
+};
+
+int die(const char* what) {
+    fprintf(stderr, "opv-demod: %s: %s\n", what, opv_last_error());
+    return 2;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Options o;
+    for (int i = 1; i < argc; ++i) {  // same hand-rolled loop as the reference (ref :950-974): unknown flags ignored
+        if (!strcmp(argv[i], "-q")) o.quiet = true;
+        else if (!strcmp(argv[i], "-r")) o.raw = true;
+        else if (!strcmp(argv[i], "-c")) o.coherent = true;
+        else if (!strcmp(argv[i], "-s")) o.streaming = true;
+        else if (!strcmp(argv[i], "-a") && i + 1 < argc) o.afc = atof(argv[++i]);
+        else if (!strcmp(argv[i], "-p") && i + 1 < argc) ++i;
+        else if (!strcmp(argv[i], "-o") && i + 1 < argc) { o.off = atof(argv[++i]); o.have_off = true; }
+        else if (!strcmp(argv[i], "--device") && i + 1 < argc) o.device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--capacity-sec") && i + 1 < argc) o.capacity_sec = atof(argv[++i]);
+        else if (!strcmp(argv[i], "-h")) {
+            fprintf(stderr, "Usage: %s [options] < input.iq\n\n", argv[0]);
+            fprintf(stderr, "Options:\n");
+            fprintf(stderr, "  -q          Quiet mode\n");
+            fprintf(stderr, "  -r          Raw output to stdout\n");
+            fprintf(stderr, "  -s          Streaming mode (for live PlutoSDR input)\n");
+            fprintf(stderr, "  -c          Coherent mode (not available in the MI355X build)\n");
+            fprintf(stderr, "  -a <bw>     AFC bandwidth (default: 0.001)\n");
+            fprintf(stderr, "  -o <hz>     Initial frequency offset (streaming mode)\n");
+            fprintf(stderr, "  -p <hz>     PLL bandwidth (coherent only; ignored)\n");
+            fprintf(stderr, "  --device <n>        HIP device ordinal (default 0)\n");
+            fprintf(stderr, "  --capacity-sec <s>  streaming capture capacity in seconds of IQ (default 120)\n");
+            fprintf(stderr, "  -h          Help\n");
+            return 0;
+        }
+    }
+    if (o.coherent) {
+        fprintf(stderr, "opv-demod: coherent mode (-c) is outside the MI355X hot path (SURVEY.md §2 #9); use the non-coherent default\n");
+        return 2;
+    }
+    if (!o.quiet) {  // ref :981-990
+        fprintf(stderr, "╔═══════════════════════════════════════════════════════════════════╗\n");
+        if (o.streaming) fprintf(stderr, "║       OPV MSK Demodulator with AFC v1.0 (streaming)              ║\n");
+        else fprintf(stderr, "║           OPV MSK Demodulator with AFC v1.0                       ║\n");
+        fprintf(stderr, "╚═══════════════════════════════════════════════════════════════════╝\n\n");
+    }
+
+    std::vector<int16_t> all;  // batch mode slurps (ref :1132-1135)
+    opv_cfg cfg{};
+    cfg.streaming = o.streaming;
+    cfg.have_init_offset = o.have_off;
+    cfg.init_offset_hz = o.off;
+    cfg.afc_alpha = o.afc;
+    cfg.device = o.device;
+
+    std::vector<char> buf(1 << 18);
+    size_t carry = 0;  // bytes of a partial sample at the end of a read
+    auto read_block = [&](std::vector<int16_t>& dst) -> long {  // returns samples appended, 0 on EOF
+        for (;;) {
+            ssize_t r = ::read(STDIN_FILENO, buf.data() + carry, buf.size() - carry);
+            if (r < 0) return -1;
+            if (r == 0) return 0;  // trailing partial sample is ignored (ref :1022)
+            const size_t have = carry + (size_t)r, ns = have / 4;
+            if (ns) {
+                const int16_t* p = reinterpret_cast<const int16_t*>(buf.data());
+                dst.insert(dst.end(), p, p + 2 * ns);
+            }
+            carry = have - ns * 4;
+            if (carry) memmove(buf.data(), buf.data() + ns * 4, carry);
+            if (ns) return (long)ns;
+        }
+    };
+
+    opv_ctx* ctx = nullptr;
+    if (o.streaming) {
+        if (!o.quiet) fprintf(stderr, "Streaming mode: processing data as it arrives...\n\n");
+        if (o.have_off && !o.quiet) fprintf(stderr, "Initial frequency offset: %.1f Hz\n", o.off);
+        cfg.max_samples = (uint64_t)std::min(o.capacity_sec * kFs, 2147483000.0);
+        if (opv_create(&ctx, 1, &cfg) < 0) return die("opv_create");
+        Sink sink{ctx, o};
+        std::vector<int16_t> blk;
+        uint64_t pushed = 0, since = 0;
+        for (;;) {
+            blk.clear();
+            long ns = read_block(blk);
+            if (ns <= 0) break;
+            if (opv_push_iq(ctx, 0, blk.data(), (size_t)ns) < 0) return die("opv_push_iq");
+            pushed += (uint64_t)ns;
+            since += (uint64_t)ns;
+            if (since >= OPV_CHUNK_SAMPLES - 64) {  // a chunk boundary may have been crossed
+                if (opv_process(ctx) < 0) return die("opv_process");
+                if (sink.drain() < 0) return die("drain");
+                since = 0;
+            }
+        }
+        if (opv_flush(ctx, 0) < 0 || opv_process(ctx) < 0) return die("opv_flush");
+        if (sink.drain() < 0) return die("drain");
+        opv_stream_state st;
+        opv_get_state(ctx, 0, &st);
+        if (!o.quiet) {  // ref :1115-1122
+            fprintf(stderr, "\n════════════════════════════════════════════════════════════════════\n");
+            fprintf(stderr, "Summary: %d frames (%d perfect, %d errors)\n", sink.decoded, sink.perfect, sink.decoded - sink.perfect);
+            fprintf(stderr, "Total: %.3f sec, %llu symbols\n", sink.full_samples / kFs, (unsigned long long)sink.full_symbols);
+            fprintf(stderr, "Final state: %s, AFC: %.1f Hz\n", state_name(st.sync_state), st.freq_offset_hz);
+            fprintf(stderr, "════════════════════════════════════════════════════════════════════\n");
+        }
+        opv_destroy(ctx);
+        return sink.decoded > 0 ? 0 : 1;
+    }
+
+    // ---- batch mode (ref :1132-1216) ----
+    for (;;) {
+        long ns = read_block(all);
+        if (ns <= 0) break;
+    }
+    const size_t n = all.size() / 2;
+    if (!o.quiet) fprintf(stderr, "Loaded %zu samples (%.3f sec)\n", n, n / kFs);
+    cfg.max_samples = n + 64;
+    if (opv_create(&ctx, 1, &cfg) < 0) return die("opv_create");
+    if (n && opv_push_iq(ctx, 0, all.data(), n) < 0) return die("opv_push_iq");
+    if (opv_flush(ctx, 0) < 0 || opv_process(ctx) < 0) return die("opv_process");
+    opv_stream_state st;
+    if (opv_get_state(ctx, 0, &st) < 0) return die("opv_get_state");
+    if (!o.quiet) {
+        fprintf(stderr, "Estimated carrier offset: %.1f Hz\n", st.est_offset_hz);  // ref :1170
+        fprintf(stderr, "Demodulated %llu symbols, final AFC offset: %.1f Hz\n\n", (unsigned long long)st.total_symbols, st.freq_offset_hz);
+    }
+    Sink sink{ctx, o};
+    if (sink.drain() < 0) return die("drain");
+    if (!o.quiet) {  // ref :1208-1214
+        fprintf(stderr, "════════════════════════════════════════════════════════════════════\n");
+        fprintf(stderr, "Summary: %d frames (%d perfect, %d errors)\n", sink.decoded, sink.perfect, sink.decoded - sink.perfect);
+        fprintf(stderr, "Final state: %s, AFC: %.1f Hz\n", state_name(st.sync_state), st.freq_offset_hz);
+        fprintf(stderr, "════════════════════════════════════════════════════════════════════\n");
+    }
+    opv_destroy(ctx);
+    return sink.decoded > 0 ? 0 : 1;
+}

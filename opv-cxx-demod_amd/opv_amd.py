@@ -31,7 +31,7 @@ EXPORTS = [
     "opv_attach_device_iq", "opv_process", "opv_sync", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_tap_soft", "opv_tap_chunks",
     "opv_tap_offset_energies", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_modulated_samples",
-    "opv_tx_modulate", "opv_channel_device",
+    "opv_tx_modulate", "opv_channel_device", "opv_enable_timing", "opv_kernel_times",
 ]
 
 
@@ -114,6 +114,8 @@ def lib():
         L.opv_tx_modulate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.opv_channel_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double,
                                          C.c_double, C.c_uint64]
+        L.opv_enable_timing.argtypes = [C.c_void_p, C.c_int]
+        L.opv_kernel_times.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -177,8 +179,17 @@ class Demod:
     def sync(self):
         _chk(lib().opv_sync(self.h))
 
-    def reset(self, stream):
+    def reset(self, stream=-1):
         _chk(lib().opv_reset_stream(self.h, stream))
+
+    def enable_timing(self, on=True):
+        _chk(lib().opv_enable_timing(self.h, int(on)))
+
+    def kernel_times(self):
+        """ms of the last process(): dict(offset_search, msk_frontend, sync_track, frame_decode)"""
+        t = (C.c_float * 4)()
+        _chk(lib().opv_kernel_times(self.h, t))
+        return dict(offset_search=t[0], msk_frontend=t[1], sync_track=t[2], frame_decode=t[3])
 
     def pop_frames(self, stream, cap=None):
         cap = cap or (int(self.cfg.max_samples) // (FRAME_SYMBOLS * 38) + 8)
