@@ -54,6 +54,7 @@ constexpr double kPi = 3.14159265358979323846;  // ref :43
 constexpr double kTwoPi = 2.0 * kPi;            // ref :44
 constexpr double kFs = 2168000.0;               // ref :40
 constexpr double kSymRate = 2168000.0 / 40.0;   // ref :41
+constexpr double kDeltaPerHz = kTwoPi / kFs;    // d = 2 pi fo / Fs (ref :210-211, :305-306)
 
 constexpr int kWin = 256;                       // fp64 window, samples (power of two)
 constexpr int kTileLds = 9216;                  // 9 x 1 KiB per tile slot (8672 used)
@@ -76,9 +77,33 @@ __device__ inline double swap16_add(double a, double b) {
 }
 template <int CTRL>
 __device__ inline double dpp_add(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, dlo(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, dhi(v), CTRL, 0xF, 0xF, false);
+    // bound_ctrl:1 => no "old" operand to materialise (every lane of a row_ror is valid anyway)
+    const int lo = __builtin_amdgcn_mov_dpp(dlo(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(dhi(v), CTRL, 0xF, 0xF, true);
     return v + mkd(hi, lo);
+}
+// d = a*b + c as a 3-operand VOP3 (hipcc otherwise copies the constant addend and uses v_fmac)
+__device__ inline double fma3(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ inline int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// p*h + c with c in an SGPR pair (a coefficient fetched through the scalar cache)
+__device__ inline double fma3s(double p, double h, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(h), "s"(c));
+    return d;
+}
+// n/d for well-scaled operands (correlator energies: 1e0..1e25, never denormal/inf): v_rcp_f64,
+// two Newton steps and one residual correction — <= 1 ulp, 6 instructions instead of the 13
+// of the IEEE expansion (div_scale/div_fmas/div_fixup only matter at the exponent extremes).
+__device__ inline double div_fast(double n, double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    y = fma(fma(-d, y, 1.0), y, y);
+    y = fma(fma(-d, y, 1.0), y, y);
+    const double q = n * y;
+    return fma(fma(-d, q, n), y, q);
 }
 // sum over the 16 lanes of a row, result in every lane of the row (row_ror 8,4,2,1)
 __device__ inline double row_allsum(double v) {
@@ -94,9 +119,14 @@ __device__ inline double readlane_d(double v, int l) {
     return mkd(__builtin_amdgcn_readlane(dhi(v), l), __builtin_amdgcn_readlane(dlo(v), l));
 }
 
-__device__ inline double clampd(double v, double lo, double hi) { return v < lo ? lo : (hi < v ? hi : v); }
+__device__ inline double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 }  // namespace
+
+#define OPV_ATAN_DIV(n, d) div_fast((n), (d))
+#define OPV_ATAN_FMAC(p, h, c) fma3s((p), (h), (c))
+#define OPV_ATAN_UNI(k) uni_i(k)
+#include "opv_atan2.h"
 
 extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __restrict__ streams,
                                                                  OpvGlobalCfg cfg) {
@@ -182,7 +212,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
 
         const double Nd = (double)N;
         double pos = mu;                                   // ref :217
-        double delta = kTwoPi * fo / kFs;                  // fo part of phase_inc (ref :210-211)
+        double delta = fo * kDeltaPerHz;                   // fo part of phase_inc (ref :210-211)
         uint32_t nsym_call = 0;
 
         while (uni((uint32_t)(pos + 40.0 + 10.0 < Nd))) {  // ref :221 (wave-uniform)
@@ -219,7 +249,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
 
             // ---- one interpolated sample per lane (ref :122-128, :232-238) -------------------
             double p = pos + kf;
-            p = p < 0.0 ? 0.0 : p;                         // early gate before the chunk: s[0] (ref :237)
+            p = fmax(p, 0.0);                              // early gate before the chunk: s[0] (ref :237)
             const int idx = (int)p;
             const double f = p - (double)idx;
             const double g1 = 1.0 - f;
@@ -233,19 +263,19 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             const double x = kf * delta;
             const double x2 = x * x;
             double sp = -1.0 / 39916800.0;                 // x^11
-            sp = fma(sp, x2, 1.0 / 362880.0);
-            sp = fma(sp, x2, -1.0 / 5040.0);
-            sp = fma(sp, x2, 1.0 / 120.0);
-            sp = fma(sp, x2, -1.0 / 6.0);
-            sp = fma(sp, x2, 1.0);
+            sp = fma3(sp, x2, 1.0 / 362880.0);
+            sp = fma3(sp, x2, -1.0 / 5040.0);
+            sp = fma3(sp, x2, 1.0 / 120.0);
+            sp = fma3(sp, x2, -1.0 / 6.0);
+            sp = fma3(sp, x2, 1.0);
             const double xs = x * sp;                      // sin
             double cp = 1.0 / 479001600.0;                 // x^12
-            cp = fma(cp, x2, -1.0 / 3628800.0);
-            cp = fma(cp, x2, 1.0 / 40320.0);
-            cp = fma(cp, x2, -1.0 / 720.0);
-            cp = fma(cp, x2, 1.0 / 24.0);
-            cp = fma(cp, x2, -0.5);
-            const double xc = fma(cp, x2, 1.0);            // cos
+            cp = fma3(cp, x2, -1.0 / 3628800.0);
+            cp = fma3(cp, x2, 1.0 / 40320.0);
+            cp = fma3(cp, x2, -1.0 / 720.0);
+            cp = fma3(cp, x2, 1.0 / 24.0);
+            cp = fma3(cp, x2, -0.5);
+            const double xc = fma3(cp, x2, 1.0);           // cos
 
             // Z = Lam * conj(X)
             const double zr = fma(lr, xc, li * xs);
@@ -286,7 +316,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             const double er = dom1 ? P1e + P2e : P1e - P2e, ei = dom1 ? P3e - P4e : P3e + P4e;
             const double lr2 = dom1 ? P1l + P2l : P1l - P2l, li2 = dom1 ? P3l - P4l : P3l + P4l;
             const double ee = er * er + ei * ei, el = lr2 * lr2 + li2 * li2;
-            const double ted = (el - ee) / (el + ee + 1e-10);       // ref :275/:279
+            const double ted = div_fast(el - ee, el + ee + 1e-10);  // ref :275/:279
 
             tf += 0.00001 * ted;                                    // beta (ref :118,:283)
             tf = clampd(tf, -0.1, 0.1);
@@ -300,37 +330,40 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 const double cr = dr * pr + di * pi;                // dom * conj(prev) (ref :299)
                 const double ci = di * pr - dr * pi;
                 double pd;
-                if (dr == 0.0 && di == 0.0) {
-                    // Digital silence: the reference's correlators are exactly (+0,+0) and its
-                    // arg() is decided by the SIGNS OF ZEROS of (+0,+0)*conj(prev): pi iff both
-                    // components of its prev_corr are negative, else 0 (IEEE atan2 of signed
-                    // zeros; ref :299 with std::complex multiply). Its prev_corr carries the
-                    // absolute LO phase, which this kernel never forms; rebuild it here (rare,
-                    // wave-uniform branch): E_2(k) = exp(j(k pi/2 + (80 pi/Fs) sum_{j<k} fo_j)).
+                const bool dom_zero = (dr == 0.0 && di == 0.0), prev_zero = (pr == 0.0 && pi == 0.0);
+                if (uni_i(dom_zero || prev_zero)) {
+                    // Digital silence on either side. The reference's product (ref :299) is then
+                    // an exact zero whose SIGNS decide std::arg: atan2(+0,-0) = pi, everything
+                    // else +/-0 (IEEE). Working the signs through its complex multiply:
+                    //   dom == (+0,+0), prev != 0 : pi iff Re(prev) < 0 and Im(prev) < 0
+                    //   prev == (+0,+0), dom != 0 : pi iff Re(dom)  < 0 and Im(dom)  < 0
+                    //   both zero                  : 0
+                    // where dom/prev are the reference's correlations, i.e. ours times the
+                    // absolute LO phasor it carries: c_t(k) = S_t(k) conj(E_t(k)),
+                    // prev_t = P_t conj(E_t(k)), E_t(k) = exp(j(-/+ k pi/2 + (80 pi/Fs) sum_{j<k} fo_j)).
+                    // Rare and wave-uniform; rebuilt here from the running sum of fo.
                     pd = 0.0;
-                    if (!(pr == 0.0 && pi == 0.0)) {
+                    if (!(dom_zero && prev_zero)) {
                         const uint64_t ksym = n_soft + soft_cnt;    // symbols before this one
                         double th = (80.0 * kPi / kFs) * fo_sum;
                         th -= kTwoPi * rint(th / kTwoPi);
                         double sn, cs;
                         sincos(th, &sn, &cs);
-                        // multiply by j^k
+                        // multiply by (-/+ j)^k : tone 1 rotates by -pi/2 per symbol, tone 2 by +pi/2
+                        const unsigned q = (unsigned)((dom1 ? (4u - (unsigned)(ksym & 3u)) : (unsigned)(ksym & 3u)) & 3u);
                         double er2 = cs, ei2 = sn;
-                        switch (ksym & 3u) {
-                            case 1: er2 = -sn; ei2 = cs; break;
-                            case 2: er2 = -cs; ei2 = -sn; break;
-                            case 3: er2 = sn; ei2 = -cs; break;
-                            default: break;
-                        }
-                        // reference prev_corr_f2 = P_2 * conj(E_2(k))
-                        const double qr = pr * er2 + pi * ei2;
-                        const double qi = pi * er2 - pr * ei2;
+                        if (q == 1u) { er2 = -sn; ei2 = cs; }
+                        else if (q == 2u) { er2 = -cs; ei2 = -sn; }
+                        else if (q == 3u) { er2 = sn; ei2 = -cs; }
+                        const double vr = dom_zero ? pr : dr, vi = dom_zero ? pi : di;
+                        const double qr = vr * er2 + vi * ei2;      // v * conj(E)
+                        const double qi = vi * er2 - vr * ei2;
                         if (qr < 0.0 && qi < 0.0) pd = kPi;
                     }
                 } else {
-                    pd = atan2(ci, cr);
+                    pd = opv_atan2(ci, cr);
                 }
-                const double ferr = pd * kSymRate / kTwoPi;         // ref :300
+                const double ferr = pd * (kSymRate / kTwoPi);       // ref :300
                 fo += afc_alpha * ferr;                             // ref :302-303
                 fo = clampd(fo, -2000.0, 2000.0);
             }
@@ -342,7 +375,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 p2r = a2r * x40c - a2i * x40s;  p2i = a2r * x40s + a2i * x40c;
             }
             fo_sum += fo_used;
-            delta = kTwoPi * fo / kFs;
+            delta = fo * kDeltaPerHz;
 
             // ---- emit the soft symbol -----------------------------------------------------------
             if (lane == (int)(soft_cnt & 63u)) soft_keep = soft;
