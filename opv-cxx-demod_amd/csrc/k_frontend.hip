@@ -33,16 +33,21 @@
 //     arg(c(k) conj(c(k-1))) = arg(S(k) conj(P(k-1))).
 //   * 12 real sums are reduced over the wave with v_permlane32_swap / v_permlane16_swap
 //     (reduce-scatter, 2 steps) + DPP row rotations, then broadcast through LDS; the scalar
-//     loop filters run redundantly on all lanes (wave-uniform, no divergence).
+//     loop filters run redundantly on all lanes (wave-uniform, no divergence). The phase
+//     detector uses a uniform-argument atan2 (opv_atan2.h) and well-scaled divisions.
 //   * int16 IQ is staged HBM -> LDS in 2168-sample frame tiles (8672 B) with direct-to-LDS
-//     16-byte loads (global_load_lds_dwordx4), double-buffered one tile ahead, then widened
-//     to fp64 into a 256-sample LDS window that the lanes interpolate from.
+//     16-byte loads (global_load_lds_dwordx4, 1 KiB per wave instruction), two tile slots
+//     forming a 4336-sample ring plus a 68-sample guard that mirrors the head of the even
+//     tile so that a lane's two interpolation taps never need a wrap test; the next tile is
+//     requested one whole tile (~54 symbols) before its first use. Lanes read their taps
+//     straight from the int16 ring (ds_read2_b32) and widen in registers.
 //   * fp64 everywhere: the 1e-5 soft contract does not need it, bit-exact quantiser/sync
 //     decisions on noisy input do. No MFMA: the per-symbol contraction is
 //     3x4x60 with a serial dependence between symbols.
 //
 // Roofline: HBM-bound on paper (4 B/sample in, 8 B/symbol out => 4.2 B/sample) but actually
-// latency-bound by the per-symbol feedback recurrence; see DESIGN.md.
+// issue/latency-bound by the per-symbol feedback recurrence (a few hundred wave instructions
+// per symbol at one wave per stream); see DESIGN.md and profiles/.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -56,8 +61,11 @@ constexpr double kFs = 2168000.0;               // ref :40
 constexpr double kSymRate = 2168000.0 / 40.0;   // ref :41
 constexpr double kDeltaPerHz = kTwoPi / kFs;    // d = 2 pi fo / Fs (ref :210-211, :305-306)
 
-constexpr int kWin = 256;                       // fp64 window, samples (power of two)
-constexpr int kTileLds = 9216;                  // 9 x 1 KiB per tile slot (8672 used)
+constexpr uint32_t kTile = OPV_TILE_SAMPLES;    // 2168 samples
+constexpr uint32_t kRing = 2 * kTile;           // 4336 samples, two tile slots
+constexpr uint32_t kGuard = 68;                 // mirror of the even slot's head (272 B)
+constexpr uint32_t kBack = 11;                  // lowest tap is floor(pos) - 10, one spare
+constexpr uint32_t kAhead = 56;                 // highest tap is floor(pos) + 54, one spare
 
 __device__ inline int dlo(double v) { return __double2loint(v); }
 __device__ inline int dhi(double v) { return __double2hiint(v); }
@@ -82,19 +90,28 @@ __device__ inline double dpp_add(double v) {
     const int hi = __builtin_amdgcn_mov_dpp(dhi(v), CTRL, 0xF, 0xF, true);
     return v + mkd(hi, lo);
 }
+// sum over the 16 lanes of a row, result in every lane of the row (row_ror 8,4,2,1)
+__device__ inline double row_allsum(double v) {
+    v = dpp_add<0x128>(v);
+    v = dpp_add<0x124>(v);
+    v = dpp_add<0x122>(v);
+    v = dpp_add<0x121>(v);
+    return v;
+}
 // d = a*b + c as a 3-operand VOP3 (hipcc otherwise copies the constant addend and uses v_fmac)
 __device__ inline double fma3(double a, double b, double c) {
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ inline int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// p*h + c with c in an SGPR pair (a coefficient fetched through the scalar cache)
-__device__ inline double fma3s(double p, double h, double c) {
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(h), "s"(c));
-    return d;
+__device__ inline double readlane_d(double v, int l) {
+    return mkd(__builtin_amdgcn_readlane(dhi(v), l), __builtin_amdgcn_readlane(dlo(v), l));
 }
+// wave-uniform floating compare -> scalar branch (the operands are identical in every lane)
+__device__ inline bool uni_lt(double a, double b) { return __builtin_amdgcn_fcmp(a, b, 4 /*FCMP_OLT*/) != 0ull; }
+
 // n/d for well-scaled operands (correlator energies: 1e0..1e25, never denormal/inf): v_rcp_f64,
 // two Newton steps and one residual correction — <= 1 ulp, 6 instructions instead of the 13
 // of the IEEE expansion (div_scale/div_fmas/div_fixup only matter at the exponent extremes).
@@ -105,39 +122,63 @@ __device__ inline double div_fast(double n, double d) {
     const double q = n * y;
     return fma(fma(-d, q, n), y, q);
 }
-// sum over the 16 lanes of a row, result in every lane of the row (row_ror 8,4,2,1)
-__device__ inline double row_allsum(double v) {
-    v = dpp_add<0x128>(v);
-    v = dpp_add<0x124>(v);
-    v = dpp_add<0x122>(v);
-    v = dpp_add<0x121>(v);
-    return v;
-}
-
-__device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ inline double readlane_d(double v, int l) {
-    return mkd(__builtin_amdgcn_readlane(dhi(v), l), __builtin_amdgcn_readlane(dlo(v), l));
-}
 
 __device__ inline double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 }  // namespace
 
-#define OPV_ATAN_DIV(n, d) div_fast((n), (d))
-#define OPV_ATAN_FMAC(p, h, c) fma3s((p), (h), (c))
-#define OPV_ATAN_UNI(k) uni_i(k)
-#include "opv_atan2.h"
+#include "opv_atan2.h"  // kOpvAtanTab (constant-memory image of the table) + host reference routine
+
+namespace {
+// Device form of opv_atan2 (same table, same steps): the coefficient row is read from the
+// LDS copy of the table with a wave-uniform address; interval 0 (|angle| < 1/32 rad of an
+// axis — the locked, clean-signal case) needs no table at all.
+__device__ inline double atan2_uniform(double y, double x, const double* tab_lds) {
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    const double r = div_fast(mn, mx);
+    int k = (int)(r * 32.0);
+    k = uni_i(k > 31 ? 31 : k);
+    double p;
+    if (k == 0) {
+        const double r2 = r * r;                       // r - r^3/3 + r^5/5 - r^7/7 + r^9/9
+        p = fma3(1.0 / 9.0, r2, -1.0 / 7.0);
+        p = fma3(p, r2, 1.0 / 5.0);
+        p = fma3(p, r2, -1.0 / 3.0);
+        p = fma3(p, r2, 1.0);
+        p = p * r;
+    } else {
+        const double h = r - ((double)k + 0.5) * (1.0 / 32.0);
+        const double2* t = reinterpret_cast<const double2*>(tab_lds + k * 10);
+        const double2 c01 = t[0], c23 = t[1], c45 = t[2], c67 = t[3], c89 = t[4];
+        p = fma3(c89.y, h, c89.x);
+        p = fma3(p, h, c67.y);
+        p = fma3(p, h, c67.x);
+        p = fma3(p, h, c45.y);
+        p = fma3(p, h, c45.x);
+        p = fma3(p, h, c23.y);
+        p = fma3(p, h, c23.x);
+        p = fma3(p, h, c01.y);
+        p = fma3(p, h, c01.x);
+    }
+    if (uni_i(ay > ax)) p = 1.57079632679489661923 - p;
+    if (uni_i(x < 0.0)) p = 3.14159265358979323846 - p;
+    return uni_i(y < 0.0) ? -p : p;
+}
+}  // namespace
 
 extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __restrict__ streams,
                                                                  OpvGlobalCfg cfg) {
     OpvStream& st = streams[blockIdx.x];
     const int lane = threadIdx.x;
 
-    // One LDS object (tiles | window | reduction scratch), 16-byte aligned.
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * kTileLds + kWin * 16 + 128];
-    unsigned char* tiles = lds;
-    double2* win = reinterpret_cast<double2*>(lds + 2 * kTileLds);
-    double* red = reinterpret_cast<double*>(lds + 2 * kTileLds + kWin * 16);
+    // One LDS object: int16 ring (2 tiles + guard) | reduction scratch | atan table.
+    constexpr int kRingBytes = (kRing + kGuard) * 4;  // 17616
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kRingBytes + 128 + 32 * 10 * 8];
+    int* ring = reinterpret_cast<int*>(lds);
+    double* red = reinterpret_cast<double*>(lds + kRingBytes);
+    double* atab = reinterpret_cast<double*>(lds + kRingBytes + 128);
+    for (int i = lane; i < 320; i += 64) atab[i] = (&kOpvAtanTab[0][0])[i];
 
     // ---- per-lane constants -------------------------------------------------------------
     const double kf = (double)(lane - 10);
@@ -152,7 +193,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
 
     // ---- carry ---------------------------------------------------------------------------
     double fo = st.freq_offset, tf = st.timing_freq, mu = st.mu;
-    const double afc_alpha = st.afc_alpha;
+    const double afc_gain = st.afc_alpha * (kSymRate / kTwoPi);  // ref :300-302
     double p1r = st.p1r, p1i = st.p1i, p2r = st.p2r, p2i = st.p2i;
     double fo_sum = st.fo_sum;
     uint32_t origin = uni((uint32_t)st.origin);
@@ -163,36 +204,49 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
     const int eof = (int)uni((uint32_t)st.eof);
     int overflow = (int)uni((uint32_t)st.overflow);
     const uint64_t cap_soft = st.cap_soft;
-    double* __restrict__ soft_out = st.soft;
     const unsigned char* iq_bytes = reinterpret_cast<const unsigned char*>(st.iq);
     const uint64_t n_bytes = (uint64_t)n_avail * 4u;
 
-    // zero the window so that lanes outside every gate never see non-finite garbage
-    for (int k = lane; k < kWin; k += 64) win[k] = make_double2(0.0, 0.0);
-
-    // ---- tile staging state (wave-uniform) -------------------------------------------------
-    uint32_t wend = origin & ~63u;                  // window is filled up to here (exclusive)
-    uint32_t t_lo = wend / OPV_TILE_SAMPLES;        // tiles t_lo, t_lo+1 are (being) staged
+    // ---- tile staging (wave-uniform state) ----------------------------------------------
+    // Direct-to-LDS 16-byte load (global_load_lds_dwordx4): lane l moves 16 B from its own global
+    // address to LDS byte (m0 + 16 l). Issued through inline asm on purpose: hipcc's waitcnt pass
+    // would otherwise drain vmcnt(0) before EVERY later LDS read it cannot disambiguate from the
+    // DMA destination (here: once per symbol, behind the soft-symbol store). Completion is
+    // awaited explicitly with s_waitcnt vmcnt(0) one tile later (see the tile events below).
+    auto glds16 = [&](const unsigned char* gsrc, uint32_t lds_byte) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(lds_byte)
+                     : "memory");
+    };
+    const uint32_t lds_base = uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds);
     auto issue_tile = [&](uint32_t t) {
-        // 9 x global_load_lds_dwordx4: lane l moves 16 B, 1 KiB per instruction, tile slot t&1
+        // tile t -> slot t&1: 8 full + 1 partial wave instruction; an even tile's first 272 B are
+        // mirrored into the guard behind the ring.
         const uint64_t base = (uint64_t)t * OPV_TILE_BYTES;
-        unsigned char* slot = tiles + (t & 1u) * kTileLds;
+        const uint32_t slot = lds_base + (t & 1u) * OPV_TILE_BYTES;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-            const uint64_t off = base + (uint64_t)r * 1024u + (uint64_t)lane * 16u;
-            if (off + 16u <= n_bytes)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(iq_bytes + off),
-                                                 (__attribute__((address_space(3))) void*)(slot + r * 1024), 16, 0, 0);
+            const uint32_t in_tile = (uint32_t)r * 1024u + (uint32_t)lane * 16u;
+            const uint64_t off = base + in_tile;
+            if (in_tile < OPV_TILE_BYTES && off + 16u <= n_bytes) glds16(iq_bytes + off, slot + (uint32_t)r * 1024u);
+        }
+        if ((t & 1u) == 0u) {
+            const uint64_t off = base + (uint64_t)lane * 16u;
+            if (lane < 17 && off + 16u <= n_bytes) glds16(iq_bytes + off, lds_base + kRing * 4u);
         }
     };
+    // lowest sample any lane can touch at the first symbol of this launch
+    uint32_t gb_prev = origin;
+    uint32_t t_lo = (origin >= kBack ? origin - kBack : 0u) / kTile;
+    uint32_t ring_b = (origin + kRing * 4u - kBack) % kRing;  // ring slot of sample floor(pos)-11
     issue_tile(t_lo);
     issue_tile(t_lo + 1u);
-    __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): both tiles landed
-    uint32_t t_waited = t_lo + 1u;                  // highest tile index known to be in LDS
-
-    // soft-symbol staging: lane (k & 63) keeps symbol k until 64 are ready (coalesced store)
-    double soft_keep = 0.0;
-    uint32_t soft_cnt = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): both tiles (and the guard) landed
+    bool evt_issue = true;               // next tile event: request tile t_lo+2 (else: wait for the newest)
+    uint32_t next_evt = (t_lo + 1u) * kTile + kBack;
+    __syncthreads();                     // atan table visible (single wave: LDS ordering only)
 
     for (;;) {
         // ---- which demodulate() call comes next (ref :1026 / :1088 / :1173) ----------------
@@ -208,56 +262,47 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             N = n_avail;
             last = true;
         }
-        if (overflow) break;
+        // worst case one symbol per 38 samples: refuse the call rather than overrun the soft log
+        if (overflow || n_soft + (uint64_t)(N / 38u + 2u) > cap_soft) { overflow = 1; break; }
 
         const double Nd = (double)N;
         double pos = mu;                                   // ref :217
         double delta = fo * kDeltaPerHz;                   // fo part of phase_inc (ref :210-211)
         uint32_t nsym_call = 0;
+        double* __restrict__ soft_call = st.soft + n_soft; // this call's slice of the soft log
 
-        while (uni((uint32_t)(pos + 40.0 + 10.0 < Nd))) {  // ref :221 (wave-uniform)
-            if (n_soft + soft_cnt >= cap_soft) { overflow = 1; break; }
-            // ---- make sure the fp64 window covers [origin+b-10, origin+b+55] ----------------
-            const uint32_t b = uni((uint32_t)(int)pos);
-            const uint32_t need_end = origin + b + 56u;
-            while (wend < need_end) {
-                const uint32_t t_first = wend / OPV_TILE_SAMPLES;
-                const uint32_t t_last = (wend + 63u) / OPV_TILE_SAMPLES;
-                if (t_first > t_lo) {
-                    // the conversion front has left tile t_lo for good: refill its slot with
-                    // tile t_lo+2 (asynchronous, consumed one whole tile = ~54 symbols later)
+        while (uni_lt(pos + 40.0 + 10.0, Nd)) {            // ref :221
+            const uint32_t b = uni((uint32_t)pos);
+            const uint32_t gb = origin + b;                // global index of floor(pos)
+            ring_b += gb - gb_prev;
+            gb_prev = gb;
+            if (ring_b >= kRing) ring_b -= kRing;
+            while (gb >= next_evt) {                       // rare: tile bookkeeping
+                if (evt_issue) {
+                    // the lowest tap has left tile t_lo for good: refill its slot with tile
+                    // t_lo+2 (asynchronous; first needed a whole tile = ~54 symbols from now)
                     issue_tile(t_lo + 2u);
                     ++t_lo;
+                    evt_issue = false;
+                    next_evt = (t_lo + 1u) * kTile - kAhead;
+                } else {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): requested a tile ago, no stall
+                    evt_issue = true;
+                    next_evt = (t_lo + 1u) * kTile + kBack;
                 }
-                if (t_last > t_waited) {
-                    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0); issued a tile ago: no stall
-                    t_waited = t_lo + 1u;
-                }
-                const uint32_t g = wend + (uint32_t)lane;
-                double re = 0.0, im = 0.0;
-                if (g < n_avail) {
-                    const uint32_t t = g / OPV_TILE_SAMPLES;
-                    const uint32_t o = g - t * OPV_TILE_SAMPLES;
-                    const int w = *reinterpret_cast<const int*>(tiles + (t & 1u) * kTileLds + o * 4u);
-                    re = (double)(int)(short)(w & 0xFFFF);  // int16 -> fp64, no scaling (ref :1023)
-                    im = (double)(w >> 16);
-                }
-                win[g & (kWin - 1)] = make_double2(re, im);
-                wend += 64u;
             }
-            __builtin_amdgcn_wave_barrier();
 
             // ---- one interpolated sample per lane (ref :122-128, :232-238) -------------------
-            double p = pos + kf;
-            p = fmax(p, 0.0);                              // early gate before the chunk: s[0] (ref :237)
+            double p = fmax(pos + kf, 0.0);                // early gate before the chunk: s[0] (ref :237)
             const int idx = (int)p;
             const double f = p - (double)idx;
             const double g1 = 1.0 - f;
-            const uint32_t w0 = (origin + (uint32_t)idx) & (kWin - 1);
-            const double2 s0 = win[w0];
-            const double2 s1 = win[(w0 + 1) & (kWin - 1)];
-            const double lr = fma(s1.x, f, s0.x * g1);
-            const double li = fma(s1.y, f, s0.y * g1);
+            const uint32_t slot = ring_b + (uint32_t)(idx - (int)b + (int)kBack);  // < kRing + 66: guard covers it
+            const int w0 = ring[slot], w1 = ring[slot + 1u];
+            const double s0r = (double)(int)(short)(w0 & 0xFFFF), s0i = (double)(w0 >> 16);  // ref :1023
+            const double s1r = (double)(int)(short)(w1 & 0xFFFF), s1i = (double)(w1 >> 16);
+            const double lr = fma(s1r, f, s0r * g1);
+            const double li = fma(s1i, f, s0i * g1);
 
             // ---- X = exp(j kf delta) by Taylor (|x| <= 0.29) --------------------------------
             const double x = kf * delta;
@@ -294,11 +339,11 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             q1 = row_allsum(q1);
             q2 = row_allsum(q2);
             // row 0: P1{E,O,L}  row 1: P2  row 2: P3  row 3: P4
-            const double x40c = readlane_d(xc, 50), x40s = readlane_d(xs, 50);  // X[40] lives in lane 50
             if ((lane & 15) == 0) {
                 double* d = red + (lane >> 4) * 3;
                 d[0] = q0; d[1] = q1; d[2] = q2;
             }
+            const double x40c = readlane_d(xc, 50), x40s = readlane_d(xs, 50);  // X[40] lives in lane 50
             __builtin_amdgcn_wave_barrier();
             const double P1e = red[0], P1o = red[1], P1l = red[2];
             const double P2e = red[3], P2o = red[4], P2l = red[5];
@@ -307,31 +352,28 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             __builtin_amdgcn_wave_barrier();
 
             // ---- uniform tail: energies, TED, loop filters (all lanes, identical) -------------
-            const double s1r = P1o + P2o, s1i = P3o - P4o;          // S_1 (tone -13550)
-            const double s2r = P1o - P2o, s2i = P3o + P4o;          // S_2 (tone +13550)
-            const double en1 = s1r * s1r + s1i * s1i;               // ref :264-265
-            const double en2 = s2r * s2r + s2i * s2i;
+            const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;        // S_1 (tone -13550)
+            const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;        // S_2 (tone +13550)
+            const double en1 = s1r_ * s1r_ + s1i_ * s1i_;           // ref :264-265
+            const double en2 = s2r_ * s2r_ + s2i_ * s2i_;
             const double soft = en2 - en1;                          // ref :268
-            const bool dom1 = en1 > en2;                            // ref :272 / :291
+            const bool dom1 = uni_lt(en2, en1);                     // e1 > e2 (ref :272 / :291)
             const double er = dom1 ? P1e + P2e : P1e - P2e, ei = dom1 ? P3e - P4e : P3e + P4e;
             const double lr2 = dom1 ? P1l + P2l : P1l - P2l, li2 = dom1 ? P3l - P4l : P3l + P4l;
             const double ee = er * er + ei * ei, el = lr2 * lr2 + li2 * li2;
             const double ted = div_fast(el - ee, el + ee + 1e-10);  // ref :275/:279
 
-            tf += 0.00001 * ted;                                    // beta (ref :118,:283)
-            tf = clampd(tf, -0.1, 0.1);
-            double adj = 0.005 * ted + tf;                          // alpha (ref :117,:285)
-            adj = clampd(adj, -2.0, 2.0);
+            tf = clampd(fma(0.00001, ted, tf), -0.1, 0.1);          // beta (ref :118,:283-284)
+            const double adj = clampd(fma(0.005, ted, tf), -2.0, 2.0);  // alpha (ref :117,:285-286)
 
             const double fo_used = fo;
             if (nsym_call > 0) {                                    // ref :289
-                const double dr = dom1 ? s1r : s2r, di = dom1 ? s1i : s2i;
+                const double dr = dom1 ? s1r_ : s2r_, di = dom1 ? s1i_ : s2i_;
                 const double pr = dom1 ? p1r : p2r, pi = dom1 ? p1i : p2i;
                 const double cr = dr * pr + di * pi;                // dom * conj(prev) (ref :299)
                 const double ci = di * pr - dr * pi;
                 double pd;
-                const bool dom_zero = (dr == 0.0 && di == 0.0), prev_zero = (pr == 0.0 && pi == 0.0);
-                if (uni_i(dom_zero || prev_zero)) {
+                if (uni_i(cr == 0.0 && ci == 0.0)) {
                     // Digital silence on either side. The reference's product (ref :299) is then
                     // an exact zero whose SIGNS decide std::arg: atan2(+0,-0) = pi, everything
                     // else +/-0 (IEEE). Working the signs through its complex multiply:
@@ -342,9 +384,10 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                     // absolute LO phasor it carries: c_t(k) = S_t(k) conj(E_t(k)),
                     // prev_t = P_t conj(E_t(k)), E_t(k) = exp(j(-/+ k pi/2 + (80 pi/Fs) sum_{j<k} fo_j)).
                     // Rare and wave-uniform; rebuilt here from the running sum of fo.
+                    const bool dom_zero = (dr == 0.0 && di == 0.0), prev_zero = (pr == 0.0 && pi == 0.0);
                     pd = 0.0;
-                    if (!(dom_zero && prev_zero)) {
-                        const uint64_t ksym = n_soft + soft_cnt;    // symbols before this one
+                    if (dom_zero != prev_zero) {
+                        const uint64_t ksym = n_soft + nsym_call;   // symbols before this one
                         double th = (80.0 * kPi / kFs) * fo_sum;
                         th -= kTwoPi * rint(th / kTwoPi);
                         double sn, cs;
@@ -361,30 +404,21 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                         if (qr < 0.0 && qi < 0.0) pd = kPi;
                     }
                 } else {
-                    pd = opv_atan2(ci, cr);
+                    pd = atan2_uniform(ci, cr, atab);
                 }
-                const double ferr = pd * (kSymRate / kTwoPi);       // ref :300
-                fo += afc_alpha * ferr;                             // ref :302-303
-                fo = clampd(fo, -2000.0, 2000.0);
+                fo = clampd(fma(afc_gain, pd, fo), -2000.0, 2000.0);  // ref :300-303
             }
             // prev <- S_t advanced by this symbol's LO rotation: (-/+ j) X[40]   (ref :309-310)
             {
-                const double a1r = s1i, a1i = -s1r;                 // S_1 * (-j)
-                const double a2r = -s2i, a2i = s2r;                 // S_2 * (+j)
+                const double a1r = s1i_, a1i = -s1r_;               // S_1 * (-j)
+                const double a2r = -s2i_, a2i = s2r_;               // S_2 * (+j)
                 p1r = a1r * x40c - a1i * x40s;  p1i = a1r * x40s + a1i * x40c;
                 p2r = a2r * x40c - a2i * x40s;  p2i = a2r * x40s + a2i * x40c;
             }
             fo_sum += fo_used;
             delta = fo * kDeltaPerHz;
 
-            // ---- emit the soft symbol -----------------------------------------------------------
-            if (lane == (int)(soft_cnt & 63u)) soft_keep = soft;
-            ++soft_cnt;
-            if ((soft_cnt & 63u) == 0u) {
-                soft_out[n_soft + lane] = soft_keep;
-                n_soft += 64;
-                soft_cnt = 0;
-            }
+            soft_call[nsym_call] = soft;                            // all lanes, same value and address
             ++nsym_call;
             pos += 40.0 + adj;                                      // ref :313
         }
@@ -398,15 +432,11 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             c[0] = fo; c[1] = tf; c[2] = mu; c[3] = (double)leftover; c[4] = (double)nsym_call;
         }
         ++n_chunks;
+        n_soft += nsym_call;
         total_samples += N;
         origin += (leftover > 0u && leftover < N) ? used : N;
         if (last) { tail_done = 1; break; }
-        if (overflow) break;
     }
-
-    // flush staged soft symbols
-    if ((uint32_t)lane < soft_cnt) soft_out[n_soft + lane] = soft_keep;
-    n_soft += soft_cnt;
 
     if (lane == 0) {
         st.freq_offset = fo; st.timing_freq = tf; st.mu = mu;
