@@ -53,6 +53,10 @@
 
 #include "opv_device.h"
 
+#ifndef OPV_ABLATE
+#define OPV_ABLATE 0  // timing experiments only; the product is always built with 0
+#endif
+
 namespace {
 
 constexpr double kPi = 3.14159265358979323846;  // ref :43
@@ -130,40 +134,29 @@ __device__ inline double clampd(double v, double lo, double hi) { return fmin(fm
 #include "opv_atan2.h"  // kOpvAtanTab (constant-memory image of the table) + host reference routine
 
 namespace {
-// Device form of opv_atan2 (same table, same steps): the coefficient row is read from the
-// LDS copy of the table with a wave-uniform address; interval 0 (|angle| < 1/32 rad of an
-// axis — the locked, clean-signal case) needs no table at all.
-__device__ inline double atan2_uniform(double y, double x, const double* tab_lds) {
-    const double ax = fabs(x), ay = fabs(y);
-    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
-    const double r = div_fast(mn, mx);
+// Device form of opv_atan2 (same table, same steps), BRANCH-FREE so that hipcc can interleave it
+// with the timing-loop arithmetic of the same symbol: the coefficient row is read from the LDS
+// copy of the table at a per-lane (identical) address, selects replace the quadrant branches.
+// r = min/max has already been formed by the caller (its divide runs beside the TED's divide).
+__device__ inline double atan_from_ratio(double r, double y, double x, const double* tab_lds) {
     int k = (int)(r * 32.0);
-    k = uni_i(k > 31 ? 31 : k);
-    double p;
-    if (k == 0) {
-        const double r2 = r * r;                       // r - r^3/3 + r^5/5 - r^7/7 + r^9/9
-        p = fma3(1.0 / 9.0, r2, -1.0 / 7.0);
-        p = fma3(p, r2, 1.0 / 5.0);
-        p = fma3(p, r2, -1.0 / 3.0);
-        p = fma3(p, r2, 1.0);
-        p = p * r;
-    } else {
-        const double h = r - ((double)k + 0.5) * (1.0 / 32.0);
-        const double2* t = reinterpret_cast<const double2*>(tab_lds + k * 10);
-        const double2 c01 = t[0], c23 = t[1], c45 = t[2], c67 = t[3], c89 = t[4];
-        p = fma3(c89.y, h, c89.x);
-        p = fma3(p, h, c67.y);
-        p = fma3(p, h, c67.x);
-        p = fma3(p, h, c45.y);
-        p = fma3(p, h, c45.x);
-        p = fma3(p, h, c23.y);
-        p = fma3(p, h, c23.x);
-        p = fma3(p, h, c01.y);
-        p = fma3(p, h, c01.x);
-    }
-    if (uni_i(ay > ax)) p = 1.57079632679489661923 - p;
-    if (uni_i(x < 0.0)) p = 3.14159265358979323846 - p;
-    return uni_i(y < 0.0) ? -p : p;
+    k = k > 31 ? 31 : k;
+    const double ck = k ? ((double)k + 0.5) * (1.0 / 32.0) : 0.0;   // interval 0 is expanded at 0
+    const double h = r - ck;
+    const double2* t = reinterpret_cast<const double2*>(tab_lds + k * 10);
+    const double2 c01 = t[0], c23 = t[1], c45 = t[2], c67 = t[3], c89 = t[4];
+    double p = fma3(c89.y, h, c89.x);
+    p = fma3(p, h, c67.y);
+    p = fma3(p, h, c67.x);
+    p = fma3(p, h, c45.y);
+    p = fma3(p, h, c45.x);
+    p = fma3(p, h, c23.y);
+    p = fma3(p, h, c23.x);
+    p = fma3(p, h, c01.y);
+    p = fma3(p, h, c01.x);
+    p = (fabs(y) > fabs(x)) ? 1.57079632679489661923 - p : p;
+    p = (x < 0.0) ? 3.14159265358979323846 - p : p;
+    return (y < 0.0) ? -p : p;
 }
 }  // namespace
 
@@ -194,7 +187,8 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
     // ---- carry ---------------------------------------------------------------------------
     double fo = st.freq_offset, tf = st.timing_freq, mu = st.mu;
     const double afc_gain = st.afc_alpha * (kSymRate / kTwoPi);  // ref :300-302
-    double p1r = st.p1r, p1i = st.p1i, p2r = st.p2r, p2i = st.p2i;
+    double q1r = st.p1r, q1i = st.p1i, q2r = st.p2r, q2i = st.p2i;   // previous on-time S_1, S_2
+    double x40c_prev = st.x40c, x40s_prev = st.x40s;                 // X[40] of that symbol
     double fo_sum = st.fo_sum;
     uint32_t origin = uni((uint32_t)st.origin);
     const uint32_t n_avail = uni((uint32_t)st.n_avail);
@@ -271,8 +265,13 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
         uint32_t nsym_call = 0;
         double* __restrict__ soft_call = st.soft + n_soft; // this call's slice of the soft log
 
-        while (uni_lt(pos + 40.0 + 10.0, Nd)) {            // ref :221
-            const uint32_t b = uni((uint32_t)pos);
+        // Tap fetch for one symbol: tile bookkeeping (wave-uniform, scalar), then each lane's two
+        // ring words. It is issued for symbol k+1 as soon as the timing loop has produced pos(k+1),
+        // so the LDS latency hides under the AFC arithmetic of symbol k (software pipelining).
+        int w0 = 0, w1 = 0;
+        double f = 0.0;
+        auto fetch = [&](double at) {
+            const uint32_t b = uni((uint32_t)at);
             const uint32_t gb = origin + b;                // global index of floor(pos)
             ring_b += gb - gb_prev;
             gb_prev = gb;
@@ -291,14 +290,19 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                     next_evt = (t_lo + 1u) * kTile + kBack;
                 }
             }
-
-            // ---- one interpolated sample per lane (ref :122-128, :232-238) -------------------
-            double p = fmax(pos + kf, 0.0);                // early gate before the chunk: s[0] (ref :237)
+            // one interpolated sample per lane (ref :122-128, :232-238)
+            const double p = fmax(at + kf, 0.0);           // early gate before the chunk: s[0] (ref :237)
             const int idx = (int)p;
-            const double f = p - (double)idx;
-            const double g1 = 1.0 - f;
+            f = p - (double)idx;
             const uint32_t slot = ring_b + (uint32_t)(idx - (int)b + (int)kBack);  // < kRing + 66: guard covers it
-            const int w0 = ring[slot], w1 = ring[slot + 1u];
+            w0 = ring[slot];
+            w1 = ring[slot + 1u];
+        };
+        bool go = uni_lt(pos + 40.0 + 10.0, Nd);           // ref :221
+        if (go) fetch(pos);
+
+        while (go) {
+            const double g1 = 1.0 - f;
             const double s0r = (double)(int)(short)(w0 & 0xFFFF), s0i = (double)(w0 >> 16);  // ref :1023
             const double s1r = (double)(int)(short)(w1 & 0xFFFF), s1i = (double)(w1 >> 16);
             const double lr = fma(s1r, f, s0r * g1);
@@ -307,6 +311,9 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             // ---- X = exp(j kf delta) by Taylor (|x| <= 0.29) --------------------------------
             const double x = kf * delta;
             const double x2 = x * x;
+#if OPV_ABLATE == 5
+            const double xs = x, xc = 1.0 - 0.5 * x2;
+#else
             double sp = -1.0 / 39916800.0;                 // x^11
             sp = fma3(sp, x2, 1.0 / 362880.0);
             sp = fma3(sp, x2, -1.0 / 5040.0);
@@ -322,6 +329,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             cp = fma3(cp, x2, -0.5);
             const double xc = fma3(cp, x2, 1.0);           // cos
 
+#endif
             // Z = Lam * conj(X)
             const double zr = fma(lr, xc, li * xs);
             const double zi = fma(li, xc, -(lr * xs));
@@ -335,10 +343,17 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             const double r0 = swap32_add(v0, v6), r1 = swap32_add(v1, v7), r2 = swap32_add(v2, v8);
             const double r3 = swap32_add(v3, v9), r4 = swap32_add(v4, v10), r5 = swap32_add(v5, v11);
             double q0 = swap16_add(r0, r3), q1 = swap16_add(r1, r4), q2 = swap16_add(r2, r5);
+#if OPV_ABLATE != 4
             q0 = row_allsum(q0);
             q1 = row_allsum(q1);
             q2 = row_allsum(q2);
+#endif
             // row 0: P1{E,O,L}  row 1: P2  row 2: P3  row 3: P4
+#if OPV_ABLATE == 2
+            const double x40c = readlane_d(xc, 50), x40s = readlane_d(xs, 50);
+            const double P1e = q0, P1o = q1, P1l = q2, P2e = q0 * 0.5, P2o = q1 * 0.25, P2l = q2 * 0.5;
+            const double P3e = q0 * 0.125, P3o = q1 * 0.5, P3l = q2 * 0.25, P4e = q0 * 0.75, P4o = q1 * 0.75, P4l = q2 * 0.125;
+#else
             if ((lane & 15) == 0) {
                 double* d = red + (lane >> 4) * 3;
                 d[0] = q0; d[1] = q1; d[2] = q2;
@@ -351,76 +366,104 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             const double P4e = red[9], P4o = red[10], P4l = red[11];
             __builtin_amdgcn_wave_barrier();
 
-            // ---- uniform tail: energies, TED, loop filters (all lanes, identical) -------------
+#endif
+
+            // ---- uniform tail (all lanes, identical). Deliberately free of branches up to the
+            // fetch of the next symbol: the timing chain (TED divide -> loop filter -> pos) and the
+            // AFC chain (phase detector divide -> atan -> fo) are independent and each is a long
+            // string of dependent fp64 operations; in one basic block hipcc interleaves them.
             const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;        // S_1 (tone -13550)
             const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;        // S_2 (tone +13550)
             const double en1 = s1r_ * s1r_ + s1i_ * s1i_;           // ref :264-265
             const double en2 = s2r_ * s2r_ + s2i_ * s2i_;
             const double soft = en2 - en1;                          // ref :268
-            const bool dom1 = uni_lt(en2, en1);                     // e1 > e2 (ref :272 / :291)
-            const double er = dom1 ? P1e + P2e : P1e - P2e, ei = dom1 ? P3e - P4e : P3e + P4e;
-            const double lr2 = dom1 ? P1l + P2l : P1l - P2l, li2 = dom1 ? P3l - P4l : P3l + P4l;
+            const bool dom1 = en2 < en1;                            // e1 > e2 (ref :272 / :291)
+            // dominant tone of the early/late gates: C = (P1 +/- P2, P3 -/+ P4); the sign is a
+            // bit flipped into the high word instead of eight selects
+            const int sgn = dom1 ? 0 : (int)0x80000000;
+            auto flip = [&](double v) { return mkd(dhi(v) ^ sgn, dlo(v)); };
+            const double er = P1e + flip(P2e), ei = P3e - flip(P4e);
+            const double lr2 = P1l + flip(P2l), li2 = P3l - flip(P4l);
             const double ee = er * er + ei * ei, el = lr2 * lr2 + li2 * li2;
+
+            // phase detector operands: dom * conj(prev) (ref :299). prev of the reference = S_prev
+            // advanced by one symbol of LO rotation, (-/+ j) X40_prev; applied to the product:
+            //   z = (S conj(S_prev)) * conj(X40_prev) * (+/- j)
+            const double dr = dom1 ? s1r_ : s2r_, di = dom1 ? s1i_ : s2i_;
+            const double pr = dom1 ? q1r : q2r, pi = dom1 ? q1i : q2i;   // previous S of that tone
+            const double ar = dr * pr + di * pi, ai = di * pr - dr * pi;
+            const double ur = fma(ar, x40c_prev, ai * x40s_prev);
+            const double ui = fma(ai, x40c_prev, -(ar * x40s_prev));
+            const double cr = mkd(dhi(ui) ^ (sgn ^ (int)0x80000000), dlo(ui));  // tone 1: -ui, tone 2: +ui
+            const double ci = mkd(dhi(ur) ^ sgn, dlo(ur));                      // tone 1: +ur, tone 2: -ur
+            const double ax = fabs(cr), ay = fabs(ci);
+            const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+            const bool degenerate = (mx == 0.0);                    // digital silence, fixed up below
+
+            // the two divides of the symbol, side by side
             const double ted = div_fast(el - ee, el + ee + 1e-10);  // ref :275/:279
+            const double ratio = div_fast(mn, degenerate ? 1.0 : mx);
 
             tf = clampd(fma(0.00001, ted, tf), -0.1, 0.1);          // beta (ref :118,:283-284)
             const double adj = clampd(fma(0.005, ted, tf), -2.0, 2.0);  // alpha (ref :117,:285-286)
+            pos += 40.0 + adj;                                      // ref :313
 
+            const double pd = atan_from_ratio(ratio, ci, cr, atab);
             const double fo_used = fo;
-            if (nsym_call > 0) {                                    // ref :289
-                const double dr = dom1 ? s1r_ : s2r_, di = dom1 ? s1i_ : s2i_;
-                const double pr = dom1 ? p1r : p2r, pi = dom1 ? p1i : p2i;
-                const double cr = dr * pr + di * pi;                // dom * conj(prev) (ref :299)
-                const double ci = di * pr - dr * pi;
-                double pd;
-                if (uni_i(cr == 0.0 && ci == 0.0)) {
-                    // Digital silence on either side. The reference's product (ref :299) is then
-                    // an exact zero whose SIGNS decide std::arg: atan2(+0,-0) = pi, everything
-                    // else +/-0 (IEEE). Working the signs through its complex multiply:
-                    //   dom == (+0,+0), prev != 0 : pi iff Re(prev) < 0 and Im(prev) < 0
-                    //   prev == (+0,+0), dom != 0 : pi iff Re(dom)  < 0 and Im(dom)  < 0
-                    //   both zero                  : 0
-                    // where dom/prev are the reference's correlations, i.e. ours times the
-                    // absolute LO phasor it carries: c_t(k) = S_t(k) conj(E_t(k)),
-                    // prev_t = P_t conj(E_t(k)), E_t(k) = exp(j(-/+ k pi/2 + (80 pi/Fs) sum_{j<k} fo_j)).
-                    // Rare and wave-uniform; rebuilt here from the running sum of fo.
-                    const bool dom_zero = (dr == 0.0 && di == 0.0), prev_zero = (pr == 0.0 && pi == 0.0);
-                    pd = 0.0;
-                    if (dom_zero != prev_zero) {
-                        const uint64_t ksym = n_soft + nsym_call;   // symbols before this one
-                        double th = (80.0 * kPi / kFs) * fo_sum;
-                        th -= kTwoPi * rint(th / kTwoPi);
-                        double sn, cs;
-                        sincos(th, &sn, &cs);
-                        // multiply by (-/+ j)^k : tone 1 rotates by -pi/2 per symbol, tone 2 by +pi/2
-                        const unsigned q = (unsigned)((dom1 ? (4u - (unsigned)(ksym & 3u)) : (unsigned)(ksym & 3u)) & 3u);
-                        double er2 = cs, ei2 = sn;
-                        if (q == 1u) { er2 = -sn; ei2 = cs; }
-                        else if (q == 2u) { er2 = -cs; ei2 = -sn; }
-                        else if (q == 3u) { er2 = sn; ei2 = -cs; }
-                        const double vr = dom_zero ? pr : dr, vi = dom_zero ? pi : di;
-                        const double qr = vr * er2 + vi * ei2;      // v * conj(E)
-                        const double qi = vi * er2 - vr * ei2;
-                        if (qr < 0.0 && qi < 0.0) pd = kPi;
+            const bool first = (nsym_call == 0);                    // no AFC on the first symbol of a call (ref :289)
+            const double fo_afc = clampd(fma(afc_gain, pd, fo), -2000.0, 2000.0);  // ref :300-303
+            fo = first ? fo : fo_afc;
+
+            if (__builtin_expect(uni_i(degenerate && !first), 0)) {
+                // Digital silence on either side. The reference's product (ref :299) is then
+                // an exact zero whose SIGNS decide std::arg: atan2(+0,-0) = pi, everything
+                // else +/-0 (IEEE). Working the signs through its complex multiply:
+                //   dom == (+0,+0), prev != 0 : pi iff Re(prev) < 0 and Im(prev) < 0
+                //   prev == (+0,+0), dom != 0 : pi iff Re(dom)  < 0 and Im(dom)  < 0
+                //   both zero                  : 0
+                // where dom/prev are the reference's correlations, i.e. ours times the
+                // absolute LO phasor it carries: c_t(k) = S_t(k) conj(E_t(k)),
+                // prev_t = P_t conj(E_t(k)), P_t = S_t(k-1) (-/+ j) X40(k-1),
+                // E_t(k) = exp(j(-/+ k pi/2 + (80 pi/Fs) sum_{j<k} fo_j)).
+                // Rare and wave-uniform; rebuilt here from the running sum of fo.
+                const bool dom_zero = (dr == 0.0 && di == 0.0), prev_zero = (pr == 0.0 && pi == 0.0);
+                double pdz = 0.0;
+                if (dom_zero != prev_zero) {
+                    const uint64_t ksym = n_soft + nsym_call;       // symbols before this one
+                    double th = (80.0 * kPi / kFs) * fo_sum;
+                    th -= kTwoPi * rint(th / kTwoPi);
+                    double sn, cs;
+                    sincos(th, &sn, &cs);
+                    // multiply by (-/+ j)^k : tone 1 rotates by -pi/2 per symbol, tone 2 by +pi/2
+                    const unsigned q = (unsigned)((dom1 ? (4u - (unsigned)(ksym & 3u)) : (unsigned)(ksym & 3u)) & 3u);
+                    double er2 = cs, ei2 = sn;
+                    if (q == 1u) { er2 = -sn; ei2 = cs; }
+                    else if (q == 2u) { er2 = -cs; ei2 = -sn; }
+                    else if (q == 3u) { er2 = sn; ei2 = -cs; }
+                    double vr = dr, vi = di;
+                    if (dom_zero) {                                 // P = S_prev * (-/+ j) * X40_prev
+                        const double jr = dom1 ? pi : -pi, ji = dom1 ? -pr : pr;
+                        vr = jr * x40c_prev - ji * x40s_prev;
+                        vi = jr * x40s_prev + ji * x40c_prev;
                     }
-                } else {
-                    pd = atan2_uniform(ci, cr, atab);
+                    const double qr = vr * er2 + vi * ei2;          // v * conj(E)
+                    const double qi = vi * er2 - vr * ei2;
+                    if (qr < 0.0 && qi < 0.0) pdz = kPi;
                 }
-                fo = clampd(fma(afc_gain, pd, fo), -2000.0, 2000.0);  // ref :300-303
+                fo = clampd(fma(afc_gain, pdz, fo_used), -2000.0, 2000.0);
             }
-            // prev <- S_t advanced by this symbol's LO rotation: (-/+ j) X[40]   (ref :309-310)
-            {
-                const double a1r = s1i_, a1i = -s1r_;               // S_1 * (-j)
-                const double a2r = -s2i_, a2i = s2r_;               // S_2 * (+j)
-                p1r = a1r * x40c - a1i * x40s;  p1i = a1r * x40s + a1i * x40c;
-                p2r = a2r * x40c - a2i * x40s;  p2i = a2r * x40s + a2i * x40c;
-            }
+            // prev <- this symbol's on-time correlations and LO rotation (ref :309-310)
+            q1r = s1r_; q1i = s1i_; q2r = s2r_; q2i = s2i_;
+            x40c_prev = x40c; x40s_prev = x40s;
             fo_sum += fo_used;
             delta = fo * kDeltaPerHz;
 
             soft_call[nsym_call] = soft;                            // all lanes, same value and address
             ++nsym_call;
-            pos += 40.0 + adj;                                      // ref :313
+
+            // ---- next symbol's taps --------------------------------------------------------------
+            go = uni_lt(pos + 40.0 + 10.0, Nd);                     // ref :221
+            if (go) fetch(pos);
         }
 
         // ---- end of this demodulate() call (ref :318-328, :1067-1076) ------------------------
@@ -440,7 +483,8 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
 
     if (lane == 0) {
         st.freq_offset = fo; st.timing_freq = tf; st.mu = mu;
-        st.p1r = p1r; st.p1i = p1i; st.p2r = p2r; st.p2i = p2i; st.fo_sum = fo_sum;
+        st.p1r = q1r; st.p1i = q1i; st.p2r = q2r; st.p2i = q2i; st.x40c = x40c_prev; st.x40s = x40s_prev;
+        st.fo_sum = fo_sum;
         st.origin = origin; st.n_soft = n_soft; st.total_samples = total_samples;
         st.n_chunks = n_chunks; st.tail_done = tail_done; st.overflow = overflow;
     }

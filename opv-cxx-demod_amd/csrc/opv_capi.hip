@@ -184,6 +184,7 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
         s.freq_offset = (cfg->streaming && cfg->have_init_offset) ? cfg->init_offset_hz : 0.0;
         s.afc_alpha = cfg->afc_alpha;  // set_afc_bandwidth (ref :1009 / :1172)
         s.est_offset = NAN;
+        s.x40c = 1.0;  // X[40] of a (non-existent) previous symbol; only ever multiplies a zero prev
         s.trk_state = OPV_HUNTING;
         c->mirror[i] = s;
     }

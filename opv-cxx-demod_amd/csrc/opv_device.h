@@ -51,9 +51,11 @@ struct OpvStream {
     double mu;
     double timing_freq;
     double afc_alpha;
-    // previous on-time correlations, stored de-rotated and pre-advanced by one symbol of LO
-    // rotation (see k_msk_frontend): P_t = S_t * exp(j 40 inc_t)
+    // previous on-time correlations S_1, S_2 in the kernel's de-rotated form, and X[40] =
+    // exp(j 40 d) of that symbol (the LO advance the reference's prev_corr implies; see
+    // k_msk_frontend)
     double p1r, p1i, p2r, p2i;
+    double x40c, x40s;
     double fo_sum;            // sum of the freq_offset used by every symbol so far (absolute LO phase, see k_frontend)
     double est_offset;        // NaN until estimate_offset ran
     double energies[134];     // offset-search tap

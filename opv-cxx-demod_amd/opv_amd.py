@@ -16,7 +16,7 @@ from pathlib import Path
 import numpy as np
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libopv_demod_hip.so"
+LIB_PATH = Path(__import__("os").environ.get("OPV_AMD_LIB", PKG / "libopv_demod_hip.so"))  # override: timing experiments only
 
 SPS = 40
 FRAME_BYTES = 134
@@ -157,11 +157,15 @@ class Demod:
         _chk(lib().opv_create(C.byref(self.h), n_streams, C.byref(self.cfg)))
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             lib().opv_destroy(self.h)
             self.h = C.c_void_p()
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     def push(self, stream, iq):
         iq = np.ascontiguousarray(iq, np.int16).reshape(-1)
