@@ -194,6 +194,19 @@ def main():
     launch_samples = float(S) * n
     achieved = launch_samples * ALGO_BYTES_PER_SAMPLE / (fe_ms * 1e-3) / 1e9
 
+    # HBM bytes of the dominant kernel come from separate rocprofv3 --pmc passes (bench.py cannot
+    # profile itself); they are only attached when this run is the profiled configuration.
+    traffic = None
+    traffic_note = "no PMC passes recorded for this configuration (see profiles/collect.sh)"
+    try:
+        tj = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())
+        w = tj["workload"]
+        if (w["streams_per_gpu"], w["frames_per_stream"], w["ebn0"]) == (S, F, args.ebn0):
+            traffic = round(tj["hbm_bytes_per_launch"] / (fe_ms * 1e-3) / 1e9, 3)
+            traffic_note = tj["source"] + "; " + tj["correction"]
+    except Exception:
+        pass
+
     out = {
         "metric": "IQ Msamples/s demod+Viterbi (×real-time @2.168MSPS); BER vs ref",
         "value": round(msps, 3), "unit": "Msamples/s", "x_realtime": round(msps / 2.168, 1),
@@ -208,9 +221,11 @@ def main():
         "frames_checked": f"rank0: {stats.get('frames_exact')}/{stats.get('frames_total')} decoded frames equal the "
                           f"transmitted bytes (rest = channel errors at {args.ebn0:g} dB); GPU==reference parity is tests/",
         "roofline": {"bound": "hbm", "kernel": "k_msk_frontend", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                     "traffic_note": traffic_note,
                      "kernel_ms": round(fe_ms, 3),
-                     "note": "latency-bound per-symbol feedback recurrence, not bandwidth (DESIGN.md)"},
+                     "note": "issue/latency-bound per-symbol feedback recurrence at 64 waves per GPU, not bandwidth "
+                             "(DESIGN.md); extras.stream_sweep shows the same kernel with the chip filled"},
         "kernel_ms": {k: round(float(np.mean([x[k] for x in kt])), 3) for k in kt[0]},
         "check": stats,
     }

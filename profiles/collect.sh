@@ -1,0 +1,33 @@
+#!/bin/bash
+# profiles/collect.sh <round-tag> — run on the GPU box (through gpurun). Produces, for the
+# default `python3 bench.py` command (the configuration the driver records):
+#   profiles/<tag>_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary
+#   profiles/<tag>_pmc_*.txt            per-kernel PMC sums (separate passes; HBM bytes per
+#                                       MI355X_MICROARCH.md §HBM: FETCH_SIZE x2 for wide reads)
+#   profiles/<tag>_bench.json           the bench line of the un-profiled run
+# Everything is written under gpurun_out/profiles_<tag>/ and merged back by gpurun; copy the
+# summaries into profiles/ afterwards (see profiles/README.md).
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/profiles_$TAG
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 900 python3 $R/bench.py 2>/dev/null | tail -1 > $O/${TAG}_bench.json
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-extras > $O/kt.log 2>&1
+cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv
+agg() { python3 - "$1" <<'PY'
+import csv,sys,collections
+agg=collections.defaultdict(float); n=collections.defaultdict(int)
+for r in csv.DictReader(open(sys.argv[1])):
+    k=(r.get('Kernel_Name','')[:40], r['Counter_Name']); agg[k]+=float(r['Counter_Value']); n[k]+=1
+for k,v in sorted(agg.items()): print("%-42s %-24s sum=%.6g dispatches=%d per_dispatch=%.6g"%(k[0],k[1],v,n[k],v/n[k]))
+PY
+}
+i=0
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout 900 rocprofv3 --pmc $C --kernel-include-regex "k_msk_frontend|k_frame_decode|k_offset_search|k_sync_track" --output-format csv -d $O/p$i -- python3 $R/bench.py --no-extras --steps 1 --warmup 0 > $O/p$i.log 2>&1
+  f=$(find $O/p$i -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && agg $f > $O/${TAG}_pmc_$i.txt
+done
+cat $O/${TAG}_bench.json; head -8 $O/${TAG}_kernel_stats.csv; cat $O/${TAG}_pmc_*.txt
