@@ -1,0 +1,61 @@
+"""CPU-only: the table-driven atan2 used by the AFC phase detector (csrc/opv_atan2.h), built
+for the host from the same header + table, against glibc atan2."""
+import subprocess
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+SRC = r'''
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "opv_atan2.h"
+int main() {
+    double maxabs = 0, maxrel = 0;
+    srand48(7);
+    for (long i = 0; i < 4000000; i++) {
+        double s = exp(drand48() * 60 - 30);
+        double y = (drand48() * 2 - 1) * s, x = (drand48() * 2 - 1) * s;
+        if (i % 5 == 0) y *= 1e-6;
+        if (i % 7 == 0) x *= 1e-4;
+        if (i % 11 == 0) { double t = x; x = y; y = t; }
+        if (x == 0 && y == 0) continue;
+        double a = opv_atan2(y, x), b = atan2(y, x), e = fabs(a - b);
+        if (e > maxabs) maxabs = e;
+        if (b != 0 && e / fabs(b) > maxrel) maxrel = e / fabs(b);
+    }
+    /* axes and diagonals */
+    double ax[][2] = {{0,1},{0,-1},{1,0},{-1,0},{1,1},{-1,1},{1,-1},{-1,-1},{1e-300,1},{1,1e-300}};
+    for (unsigned k = 0; k < sizeof ax / sizeof ax[0]; k++) {
+        double e = fabs(opv_atan2(ax[k][0], ax[k][1]) - atan2(ax[k][0], ax[k][1]));
+        if (e > maxabs) maxabs = e;
+    }
+    printf("%.3e %.3e\n", maxabs, maxrel);
+    return 0;
+}
+'''
+
+
+def test_atan2_table_matches_libm(tmp_path):
+    c = tmp_path / "t.cpp"
+    c.write_text(SRC)
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", str(ROOT / "opv-cxx-demod_amd" / "csrc"), str(c), "-o",
+                    str(exe), "-lm"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    maxabs, maxrel = float(out[0]), float(out[1])
+    assert maxabs < 5e-16        # 1 ulp of pi
+    assert maxrel < 4e-16
+
+
+def test_table_is_reproducible(tmp_path):
+    """The committed table equals what tools/gen_atan_table.py generates (mpmath, 60 digits)."""
+    import shutil
+    pkg = ROOT / "opv-cxx-demod_amd"
+    inc = pkg / "csrc" / "opv_atan_table.inc"
+    before = inc.read_text()
+    shutil.copy(inc, tmp_path / "keep.inc")
+    try:
+        subprocess.run(["python3", str(pkg / "tools" / "gen_atan_table.py")], check=True, capture_output=True)
+        assert inc.read_text() == before
+    finally:
+        shutil.copy(tmp_path / "keep.inc", inc)

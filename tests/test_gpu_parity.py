@@ -219,3 +219,68 @@ def test_errors_are_loud(amd):
     with pytest.raises(amd.OpvError):
         d.push(0, np.zeros(20, np.int16))           # push after flush
     d.close()
+
+
+# ------------------------------------------------------------------ full-size cases
+def test_config1_full_size_vs_reference_hashes(amd, golden):
+    """BASELINE configs[1] at full size: 1000 clean frames, one stream. The input is the product's
+    own modulator (sha256-pinned to `opv-mod -S W5NYV -B 1000`); the decoded bytes and the tracker
+    event text must hash to what the REFERENCE BINARY produced (tests/golden/golden.json)."""
+    _, meta = golden
+    pins = meta["opv_mod_bert_W5NYV"]
+    tx = amd.bert_frames(1000)
+    iq = amd.modulate(tx)
+    assert hashlib.sha256(iq.tobytes()).hexdigest() == pins["1000"]["sha256"]
+    d = amd.Demod(1, max_samples=iq.size // 2 + 64, streaming=True)
+    d.push(0, iq)
+    d.flush(0)
+    d.process()
+    fr, meta_f = d.pop_frames(0)
+    assert hashlib.sha256(fr.tobytes()).hexdigest() == pins["1000_frames_stream"]["sha256"]
+    ev = "\n".join(amd.format_events(d.pop_events(0)))
+    assert hashlib.sha256(ev.encode()).hexdigest() == pins["1000_frames_stream"]["events_sha256"]
+    assert np.array_equal(fr, tx) and (meta_f["viterbi_metric"] == 0).all()
+    st = d.state(0)
+    assert st.frames_decoded == 1000 and st.frames_perfect == 1000 and st.est_offset_hz == 1430.0
+    d.close()
+
+
+def test_64_streams_device_channel_round_trip(amd, oracle):
+    """BASELINE configs[3] shape: 64 concurrent streams from the device channel tool (HBM-resident,
+    zero-copy attach). Size-independent properties: every stream releases every frame, in order;
+    noiseless streams decode every frame exactly; two sampled streams equal the oracle bit for bit."""
+    import ctypes as C
+    import torch
+    F, S = 60, 64
+    tx = amd.bert_frames(F)
+    base = amd.modulate(tx)
+    n = base.size // 2
+    dev = torch.device("cuda", 0)
+    d_base = torch.from_numpy(base).to(dev)
+    d_iq = torch.empty((S, 2 * n), dtype=torch.int16, device=dev)
+    d = amd.Demod(S, max_samples=n + 64, streaming=True)
+    for k in range(S):
+        sigma = 0.0 if k % 2 == 0 else 2005.0        # odd streams: 16 dB
+        d.channel(d_base.data_ptr(), d_iq[k].data_ptr(), n, gain=2000.0 / 16383.0, f0_hz=-1500.0 + 3000.0 * k / 63,
+                  sigma=sigma, seed=77 + k)
+    d.sync()
+    for k in range(S):
+        d.attach(k, d_iq[k].data_ptr(), n, eof=True)
+    d.process()
+    d.sync()
+    for k in range(S):
+        fr, meta = d.pop_frames(k)
+        assert len(fr) == F, k
+        if k % 2 == 0:
+            assert np.array_equal(fr, tx), k
+        else:
+            assert (fr == tx).all(axis=1).mean() > 0.95, k
+        assert np.array_equal(meta["release_symbol"][1:] - meta["release_symbol"][:-1], np.full(F - 1, 2168)), k
+    for k in (5, 62):
+        x = d_iq[k].cpu().numpy()
+        exp = oracle.receive(x, streaming=True)
+        d2 = amd.Demod(1, max_samples=n + 64, streaming=True)
+        got = d2.receive([x])[0]
+        check_stream(amd, got, exp, f"device-channel stream {k}")
+        d2.close()
+    d.close()
