@@ -61,7 +61,9 @@ typedef struct opv_cfg {
     double afc_alpha;         /* -a value; 0.001 if <= 0 is NOT substituted: pass 0.001 for the default (:945) */
     int32_t device;           /* HIP device ordinal */
     int32_t keep_soft;        /* reserved (soft symbols are always retained in this version) */
-    uint64_t max_samples;     /* per-stream capacity in IQ samples (sizes the device logs) */
+    uint64_t max_samples;     /* per-stream DEVICE BUFFER capacity in IQ samples (< 2^31). Pushed streams may be
+                                 arbitrarily long: consumed samples / soft symbols are dropped when the buffer
+                                 fills (>= ~3 chunks + the largest push is enough); an attached capture must fit */
 } opv_cfg;
 
 /* Per decoded frame: what main() knows when it prints/writes a frame
@@ -156,9 +158,11 @@ int opv_device_frames(opv_ctx* ctx, const uint8_t** d_frames, const int32_t** d_
 void* opv_hip_stream(opv_ctx* ctx);
 
 /* ---- parity taps (debug): the intermediates the 1e-5 contract is checked on ------------ */
+/* soft symbols by absolute symbol index; only the retained tail of a long pushed stream is available */
 long opv_tap_soft(opv_ctx* ctx, int stream, uint64_t first_symbol, double* out, size_t cap);
-/* per demodulate() call: {freq_offset, timing_freq, mu, leftover, n_symbols} */
-long opv_tap_chunks(opv_ctx* ctx, int stream, double* out5, size_t cap_chunks);
+/* per demodulate() call, starting at call number first_chunk: {freq_offset, timing_freq, mu,
+ * leftover, n_symbols}. The log is a ring of the most recent calls. */
+long opv_tap_chunks(opv_ctx* ctx, int stream, uint32_t first_chunk, double* out5, size_t cap_chunks);
 /* 134 candidate energies of the offset search in scan order (121 coarse, 13 fine) */
 int opv_tap_offset_energies(opv_ctx* ctx, int stream, double* out134);
 

@@ -62,7 +62,8 @@ struct DecodeTaps {
 };
 
 // The whole FrameDecoder::decode for one frame, executed by one wave.
-__device__ inline void decode_one(const double* __restrict__ soft, uint8_t* __restrict__ out,
+__device__ inline void decode_one(const double* __restrict__ soft, uint32_t first, uint32_t mask,
+                                  uint8_t* __restrict__ out,
                                   int32_t* __restrict__ metric_out, int8_t* tq, int8_t* td, uint8_t* tb,
                                   unsigned char* lds) {
     const int lane = threadIdx.x;
@@ -72,7 +73,7 @@ __device__ inline void decode_one(const double* __restrict__ soft, uint8_t* __re
     uint8_t* s_d = s_q + OPV_CODED;                                                  //  2 144 B
     uint8_t* s_out = s_d + OPV_CODED;                                                //    136 B
 
-    for (int i = lane; i < OPV_CODED; i += 64) s_soft[i] = soft[i];
+    for (int i = lane; i < OPV_CODED; i += 64) s_soft[i] = soft[(first + (uint32_t)i) & mask];  // ring or linear (mask = ~0)
     __syncthreads();
 
     // ---- scale = mean |soft|, summed in index order (ref :856-858) --------------------------
@@ -164,11 +165,11 @@ extern "C" __global__ __launch_bounds__(64) void k_frame_decode(OpvStream* __res
     __shared__ __attribute__((aligned(16))) unsigned char lds[kDecodeLds];
     OpvStream& st = streams[blockIdx.y];
     const uint32_t f = st.dec_from + blockIdx.x;
-    const uint32_t nf = st.n_frames < st.cap_frames ? st.n_frames : st.cap_frames;
-    if (f >= nf) return;
-    const OpvFrameRec rec = st.frec[f];
-    decode_one(st.soft + rec.payload_sym, st.frames + (size_t)f * OPV_FB, st.metrics + f, nullptr, nullptr,
-               nullptr, lds);
+    if (f >= st.n_frames) return;
+    const uint32_t slot = f % st.cap_frames;  // frame records / frames / metrics are rings
+    const OpvFrameRec rec = st.frec[slot];
+    decode_one(st.soft, (uint32_t)rec.payload_sym, (uint32_t)(st.cap_soft - 1), st.frames + (size_t)slot * OPV_FB,
+               st.metrics + slot, nullptr, nullptr, nullptr, lds);
 }
 
 // stand-alone decoder over caller-provided payloads (parity tap / opv_decode_payloads)
@@ -179,7 +180,7 @@ extern "C" __global__ __launch_bounds__(64) void k_decode_payloads(const double*
     __shared__ __attribute__((aligned(16))) unsigned char lds[kDecodeLds];
     const uint32_t f = blockIdx.x;
     if (f >= n) return;
-    decode_one(soft + (size_t)f * OPV_CODED, out + (size_t)f * OPV_FB, metrics + f,
+    decode_one(soft + (size_t)f * OPV_CODED, 0u, 0xFFFFFFFFu, out + (size_t)f * OPV_FB, metrics + f,
                q ? q + (size_t)f * OPV_CODED : nullptr, deint ? deint + (size_t)f * OPV_CODED : nullptr,
                bits ? bits + (size_t)f * OPV_FBITS : nullptr, lds);
 }

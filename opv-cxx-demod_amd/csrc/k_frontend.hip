@@ -198,6 +198,12 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
     const int eof = (int)uni((uint32_t)st.eof);
     int overflow = (int)uni((uint32_t)st.overflow);
     const uint64_t cap_soft = st.cap_soft;
+    // oldest soft symbol the tracker may still read: its 24-symbol window, or the payload / next
+    // sync check hanging off the current anchor
+    uint64_t soft_keep = st.trk_next >= 24 ? st.trk_next - 24 : 0;
+    if (st.trk_state != 0 && st.trk_anchor < soft_keep) soft_keep = st.trk_anchor;
+    const uint32_t soft_mask = (uint32_t)(cap_soft - 1);
+    double* __restrict__ soft_ring = st.soft;
     const unsigned char* iq_bytes = reinterpret_cast<const unsigned char*>(st.iq);
     const uint64_t n_bytes = (uint64_t)n_avail * 4u;
 
@@ -257,13 +263,13 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             last = true;
         }
         // worst case one symbol per 38 samples: refuse the call rather than overrun the soft log
-        if (overflow || n_soft + (uint64_t)(N / 38u + 2u) > cap_soft) { overflow = 1; break; }
+        if (overflow || (n_soft - soft_keep) + (uint64_t)(N / 38u + 2u) > cap_soft) { overflow = 1; break; }
 
         const double Nd = (double)N;
         double pos = mu;                                   // ref :217
         double delta = fo * kDeltaPerHz;                   // fo part of phase_inc (ref :210-211)
         uint32_t nsym_call = 0;
-        double* __restrict__ soft_call = st.soft + n_soft; // this call's slice of the soft log
+        const uint32_t soft_pos0 = (uint32_t)n_soft & soft_mask;  // ring slot of this call's first symbol
 
         // Tap fetch for one symbol: tile bookkeeping (wave-uniform, scalar), then each lane's two
         // ring words. It is issued for symbol k+1 as soon as the timing loop has produced pos(k+1),
@@ -458,7 +464,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             fo_sum += fo_used;
             delta = fo * kDeltaPerHz;
 
-            soft_call[nsym_call] = soft;                            // all lanes, same value and address
+            soft_ring[(soft_pos0 + nsym_call) & soft_mask] = soft;  // all lanes, same value and address
             ++nsym_call;
 
             // ---- next symbol's taps --------------------------------------------------------------
@@ -470,8 +476,8 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
         const uint32_t used = uni((uint32_t)pos);
         mu = pos - (double)used;
         const uint32_t leftover = N - used;
-        if (lane == 0 && n_chunks < st.cap_chunks) {
-            double* c = st.chunk_log + 5 * (size_t)n_chunks;
+        if (lane == 0) {                                   // chunk log is a ring
+            double* c = st.chunk_log + 5 * (size_t)(n_chunks % st.cap_chunks);
             c[0] = fo; c[1] = tf; c[2] = mu; c[3] = (double)leftover; c[4] = (double)nsym_call;
         }
         ++n_chunks;

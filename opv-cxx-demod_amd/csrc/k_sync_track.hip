@@ -25,12 +25,12 @@ namespace {
 struct Corr { double raw, norm; };
 
 // ref :743-757
-__device__ inline Corr window_corr(const double* __restrict__ soft, uint64_t last) {
-    const double* w = soft + (last - (OPV_SYNC_BITS - 1));
+__device__ inline Corr window_corr(const double* __restrict__ soft, uint32_t mask, uint64_t last) {
+    const uint32_t w0 = (uint32_t)(last - (OPV_SYNC_BITS - 1));  // the soft log is a power-of-two ring
     double sum = 0.0, energy = 0.0;
 #pragma unroll
     for (int i = 0; i < OPV_SYNC_BITS; ++i) {
-        const double s = w[i];
+        const double s = soft[(w0 + (uint32_t)i) & mask];
         const double pat = ((OPV_SYNC_WORD >> (OPV_SYNC_BITS - 1 - i)) & 1u) ? -1.0 : 1.0;  // ref :597-600
         sum += s * pat;
         energy += fabs(s);
@@ -47,6 +47,7 @@ extern "C" __global__ __launch_bounds__(64) void k_sync_track(OpvStream* __restr
     OpvStream& st = streams[blockIdx.x];
     const int lane = threadIdx.x;
     const double* __restrict__ soft = st.soft;
+    const uint32_t mask = (uint32_t)(st.cap_soft - 1);
     const uint64_t n = st.n_soft;
 
     int state = st.trk_state, collecting = st.trk_collecting, misses = st.trk_misses;
@@ -57,18 +58,18 @@ extern "C" __global__ __launch_bounds__(64) void k_sync_track(OpvStream* __restr
     if (lane == 0) st.dec_from = n_frames;
 
     auto event = [&](int kind, int count, uint64_t sym, double corr, double raw) {
-        if (n_events < st.cap_events) {
+        if (n_events - st.events_popped < st.cap_events) {  // ring of unread events
             if (lane == 0) {
-                OpvEventRec& e = st.events[n_events];
+                OpvEventRec& e = st.events[n_events % st.cap_events];
                 e.kind = kind; e.count = count; e.sym_idx = sym; e.corr = corr; e.raw = raw;
             }
         } else overflow = 1;
         ++n_events;
     };
     auto release = [&](uint64_t at) {  // ref :660-668 / :721-729
-        if (n_frames < st.cap_frames) {
+        if (n_frames - st.frames_popped < st.cap_frames) {  // ring of unread frames
             if (lane == 0) {
-                OpvFrameRec& f = st.frec[n_frames];
+                OpvFrameRec& f = st.frec[n_frames % st.cap_frames];
                 f.payload_sym = anchor + 1;
                 f.release_sym = at;
                 f.quality = quality;
@@ -88,7 +89,7 @@ extern "C" __global__ __launch_bounds__(64) void k_sync_track(OpvStream* __restr
                 Corr c = {0.0, 0.0};
                 bool ok = false;
                 if (cand < n) {
-                    c = window_corr(soft, cand);
+                    c = window_corr(soft, mask, cand);
                     ok = (c.raw >= 5000.0) && (c.norm >= 0.85);  // ref :642
                 }
                 const unsigned long long m = __ballot(ok);
@@ -126,7 +127,7 @@ extern "C" __global__ __launch_bounds__(64) void k_sync_track(OpvStream* __restr
             }
             const uint64_t c = anchor + OPV_FSYMS;  // ref :684
             if (c >= n) break;
-            const Corr k = window_corr(soft, c);
+            const Corr k = window_corr(soft, mask, c);
             next = c + 1;
             if (k.norm >= 0.70) {  // ref :688
                 misses = 0;

@@ -46,22 +46,26 @@ struct StreamIn {  // host -> device per-round update
     uint64_t n_avail;
     int32_t eof;
     int32_t dirty;
+    uint32_t frames_popped, events_popped;  // consumer cursors of the record rings
 };
 
 __global__ void k_apply_inputs(OpvStream* streams, const StreamIn* in, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && in[i].dirty) {
-        streams[i].iq = in[i].iq;
-        streams[i].n_avail = in[i].n_avail;
-        streams[i].eof = in[i].eof;
+    if (i < n) {
+        if (in[i].dirty) {
+            streams[i].iq = in[i].iq;
+            streams[i].n_avail = in[i].n_avail;
+            streams[i].eof = in[i].eof;
+        }
+        streams[i].frames_popped = in[i].frames_popped;
+        streams[i].events_popped = in[i].events_popped;
     }
 }
 
 __global__ void k_collect_counts(const OpvStream* streams, int32_t* counts, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        const uint32_t f = streams[i].n_frames < streams[i].cap_frames ? streams[i].n_frames : streams[i].cap_frames;
-        counts[i] = (int32_t)f;
+        counts[i] = (int32_t)streams[i].n_frames;
     }
 }
 
@@ -80,6 +84,7 @@ struct HostStream {
     uint64_t last_round_avail = 0;
     uint32_t popped = 0;        // frame records already handed out
     uint32_t events_popped = 0;
+    int32_t decoded = 0, perfect = 0;  // over popped frames (`decoded` / `perfect` of main(), ref :1053-1054)
 };
 
 }  // namespace
@@ -140,7 +145,8 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
     c->mirror.resize(n_streams);
 
     const uint64_t M = cfg->max_samples;
-    c->cap_soft = M / 38 + 128;
+    c->cap_soft = 1;  // power-of-two ring: one opv_process worth of symbols (<= M/38) + a frame in flight
+    while (c->cap_soft < M / 38 + 4096) c->cap_soft <<= 1;
     c->cap_frames = (uint32_t)(M / (uint64_t)(OPV_FSYMS * 38) + 4);
     c->cap_events = 4 * c->cap_frames + 64;
     c->cap_chunks = (uint32_t)(M / 80000 + 4);
@@ -217,6 +223,40 @@ static int check_stream(opv_ctx* c, int s) {
     return OPV_OK;
 }
 
+// Long-running streams: the per-stream device buffers are bounded (opv_cfg.max_samples). When a
+// push would overflow the IQ buffer, everything the kernels can no longer touch is dropped:
+// IQ before the current chunk origin (minus the 16-sample reach of the early gate / tile
+// alignment). The soft-symbol log and the frame / event / chunk records are rings on the device
+// and need no host action. Indices handed to the caller stay absolute.
+static int compact_stream(opv_ctx* c, int s) {
+    if (int r = c->refresh()) return r;  // synchronises: no kernel is touching the buffers
+    HostStream& h = c->hs[s];
+    OpvStream st = c->mirror[s];
+    bool changed = false;
+    const uint64_t keep = st.origin >= 16 ? ((st.origin - 16) & ~3ull) : 0;
+    if (keep > 0 && h.d_iq_owned) {
+        const uint64_t len = h.n_avail - keep;  // samples to retain (less than two chunks in steady state)
+        int16_t* tmp = nullptr;
+        if (len) {
+            HIPCHK(hipMalloc(&tmp, len * 4));
+            HIPCHK(hipMemcpy(tmp, h.d_iq_owned + 2 * keep, len * 4, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(h.d_iq_owned, tmp, len * 4, hipMemcpyDeviceToDevice));
+            HIPCHK(hipFree(tmp));
+        }
+        h.n_avail -= keep;
+        h.last_round_avail = h.last_round_avail > keep ? h.last_round_avail - keep : 0;
+        st.origin -= keep;
+        st.n_avail = h.n_avail;
+        st.iq_base += keep;
+        changed = true;
+    }
+    if (changed) {
+        HIPCHK(hipMemcpy(c->d_streams + s, &st, sizeof st, hipMemcpyHostToDevice));
+        c->mirror[s] = st;
+    }
+    return OPV_OK;
+}
+
 extern "C" int opv_push_iq(opv_ctx* c, int s, const int16_t* iq, size_t n) {
     if (int r = check_stream(c, s)) return r;
     HostStream& h = c->hs[s];
@@ -224,8 +264,13 @@ extern "C" int opv_push_iq(opv_ctx* c, int s, const int16_t* iq, size_t n) {
     if (h.eof) return fail(OPV_ESTATE, "push after flush");
     if (n == 0) return OPV_OK;
     if (!iq) return fail(OPV_EINVAL, "null IQ pointer");
-    if (h.n_avail + n > c->cfg.max_samples) return fail(OPV_ECAPACITY, "opv_cfg.max_samples exceeded");
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (h.n_avail + n > c->cfg.max_samples) {
+        if (int r = compact_stream(c, s)) return r;
+        if (h.n_avail + n > c->cfg.max_samples)
+            return fail(OPV_ECAPACITY, "opv_cfg.max_samples exceeded (unprocessed samples + this push do not fit; "
+                                       "call opv_process between pushes or raise max_samples)");
+    }
     if (!h.d_iq_owned) {
         h.iq_cap = c->cfg.max_samples;
         HIPCHK(hipMalloc(&h.d_iq_owned, h.iq_cap * 4 + 16384));  // + slack for whole-tile reads
@@ -271,7 +316,7 @@ extern "C" int opv_process(opv_ctx* c) {
     bool any = false;
     for (int i = 0; i < S; ++i) {
         HostStream& h = c->hs[i];
-        in[i] = {h.d_iq, h.n_avail, h.eof, h.dirty ? 1 : 0};
+        in[i] = {h.d_iq, h.n_avail, h.eof, h.dirty ? 1 : 0, h.popped, h.events_popped};
         if (h.dirty) any = true;
         const uint64_t fresh = h.n_avail - h.last_round_avail;
         if (fresh > max_new) max_new = fresh;
@@ -355,33 +400,34 @@ extern "C" long opv_pop_frames(opv_ctx* c, int s, uint8_t* out, size_t cap, opv_
     if (int r = check_stream(c, s)) return r;
     if (int r = c->refresh()) return r;
     const OpvStream& st = c->mirror[s];
-    if (st.overflow) return fail(OPV_ECAPACITY, "a device log overflowed (raise opv_cfg.max_samples)");
+    if (st.overflow) return fail(OPV_ECAPACITY, "a device log overflowed (pop more often or raise opv_cfg.max_samples)");
     HostStream& h = c->hs[s];
-    const uint32_t nf = st.n_frames < st.cap_frames ? st.n_frames : st.cap_frames;
+    const uint32_t nf = st.n_frames;
     if (h.popped >= nf || cap == 0) return 0;
-    const uint32_t pending = nf - h.popped;
-    std::vector<int32_t> met(pending);
-    std::vector<OpvFrameRec> rec(pending);
-    std::vector<uint8_t> fr((size_t)pending * OPV_FB);
-    HIPCHK(hipMemcpy(met.data(), st.metrics + h.popped, sizeof(int32_t) * pending, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(rec.data(), st.frec + h.popped, sizeof(OpvFrameRec) * pending, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(fr.data(), st.frames + (size_t)h.popped * OPV_FB, fr.size(), hipMemcpyDeviceToHost));
     size_t w = 0;
-    uint32_t k = 0;
-    for (; k < pending && w < cap; ++k) {
-        if (met[k] == INT32_MIN) break;           // released but not decoded yet (cannot happen after opv_process)
-        if (met[k] < 0) continue;                 // dropped silent frame (ref :859, :1052)
-        if (out) std::memcpy(out + w * OPV_FB, fr.data() + (size_t)k * OPV_FB, OPV_FB);
+    uint32_t f = h.popped;
+    for (; f < nf && w < cap; ++f) {
+        const uint32_t slot = f % st.cap_frames;  // records are rings
+        int32_t met;
+        HIPCHK(hipMemcpy(&met, st.metrics + slot, sizeof met, hipMemcpyDeviceToHost));
+        if (met == INT32_MIN) break;              // released but not decoded yet (cannot happen after opv_process)
+        if (met < 0) continue;                    // dropped silent frame (ref :859, :1052)
+        OpvFrameRec rec;
+        HIPCHK(hipMemcpy(&rec, st.frec + slot, sizeof rec, hipMemcpyDeviceToHost));
+        if (out) HIPCHK(hipMemcpy(out + w * OPV_FB, st.frames + (size_t)slot * OPV_FB, OPV_FB, hipMemcpyDeviceToHost));
         if (meta) {
-            meta[w].viterbi_metric = met[k];
+            meta[w].viterbi_metric = met;
             meta[w].reserved = 0;
-            meta[w].sync_quality = rec[k].quality;
-            meta[w].release_symbol = rec[k].release_sym;
-            meta[w].payload_symbol = rec[k].payload_sym;
+            meta[w].sync_quality = rec.quality;
+            meta[w].release_symbol = rec.release_sym;
+            meta[w].payload_symbol = rec.payload_sym;
         }
+        ++h.decoded;
+        if (met == 0) ++h.perfect;
         ++w;
     }
-    h.popped += k;
+    h.popped = f;
+    h.dirty = h.dirty;  // cursors travel with the next opv_process
     return (long)w;
 }
 
@@ -390,12 +436,15 @@ extern "C" long opv_pop_events(opv_ctx* c, int s, opv_event* out, size_t cap) {
     if (int r = c->refresh()) return r;
     const OpvStream& st = c->mirror[s];
     HostStream& h = c->hs[s];
-    const uint32_t ne = st.n_events < st.cap_events ? st.n_events : st.cap_events;
+    const uint32_t ne = st.n_events;
     if (h.events_popped >= ne || cap == 0 || !out) return 0;
     uint32_t n = ne - h.events_popped;
     if (n > cap) n = (uint32_t)cap;
     static_assert(sizeof(opv_event) == sizeof(OpvEventRec), "event layouts must match");
-    HIPCHK(hipMemcpy(out, st.events + h.events_popped, sizeof(OpvEventRec) * n, hipMemcpyDeviceToHost));
+    const uint32_t first = h.events_popped % st.cap_events;
+    const uint32_t run = n < st.cap_events - first ? n : st.cap_events - first;  // up to the ring's end
+    HIPCHK(hipMemcpy(out, st.events + first, sizeof(OpvEventRec) * run, hipMemcpyDeviceToHost));
+    if (run < n) HIPCHK(hipMemcpy(out + run, st.events, sizeof(OpvEventRec) * (n - run), hipMemcpyDeviceToHost));
     h.events_popped += n;
     return (long)n;
 }
@@ -417,13 +466,13 @@ extern "C" int opv_get_state(opv_ctx* c, int s, opv_stream_state* out) {
     out->frames_released = (int32_t)st.n_frames;
     out->n_chunks = (int32_t)st.n_chunks;
     out->flushed = st.tail_done;
-    const uint32_t nf = st.n_frames < st.cap_frames ? st.n_frames : st.cap_frames;
-    if (nf) {
-        std::vector<int32_t> met(nf);
-        HIPCHK(hipMemcpy(met.data(), st.metrics, sizeof(int32_t) * nf, hipMemcpyDeviceToHost));
-        for (int32_t m : met) {
-            if (m >= 0) { out->frames_decoded++; if (m == 0) out->frames_perfect++; }
-        }
+    const HostStream& h = c->hs[s];
+    out->frames_decoded = h.decoded;
+    out->frames_perfect = h.perfect;
+    for (uint32_t f = h.popped; f < st.n_frames; ++f) {  // released but not popped yet
+        int32_t m;
+        HIPCHK(hipMemcpy(&m, st.metrics + (f % st.cap_frames), sizeof m, hipMemcpyDeviceToHost));
+        if (m >= 0) { out->frames_decoded++; if (m == 0) out->frames_perfect++; }
     }
     return st.overflow ? fail(OPV_ECAPACITY, "a device log overflowed") : OPV_OK;
 }
@@ -444,20 +493,29 @@ extern "C" long opv_tap_soft(opv_ctx* c, int s, uint64_t first, double* out, siz
     if (int r = check_stream(c, s)) return r;
     if (int r = c->refresh()) return r;
     const OpvStream& st = c->mirror[s];
+    if (st.n_soft > st.cap_soft && first < st.n_soft - st.cap_soft)
+        return fail(OPV_EINVAL, "soft symbols that old have been overwritten (the log is a ring)");
     if (first >= st.n_soft || cap == 0 || !out) return 0;
     uint64_t n = st.n_soft - first;
     if (n > cap) n = cap;
-    HIPCHK(hipMemcpy(out, st.soft + first, sizeof(double) * n, hipMemcpyDeviceToHost));
+    const uint64_t p0 = first & (st.cap_soft - 1);
+    const uint64_t run = n < st.cap_soft - p0 ? n : st.cap_soft - p0;
+    HIPCHK(hipMemcpy(out, st.soft + p0, sizeof(double) * run, hipMemcpyDeviceToHost));
+    if (run < n) HIPCHK(hipMemcpy(out + run, st.soft, sizeof(double) * (n - run), hipMemcpyDeviceToHost));
     return (long)n;
 }
 
-extern "C" long opv_tap_chunks(opv_ctx* c, int s, double* out5, size_t cap) {
+extern "C" long opv_tap_chunks(opv_ctx* c, int s, uint32_t first, double* out5, size_t cap) {
     if (int r = check_stream(c, s)) return r;
     if (int r = c->refresh()) return r;
     const OpvStream& st = c->mirror[s];
-    uint32_t n = st.n_chunks < st.cap_chunks ? st.n_chunks : st.cap_chunks;
+    if (first >= st.n_chunks || cap == 0 || !out5) return 0;
+    if (st.n_chunks - first > st.cap_chunks) return fail(OPV_EINVAL, "chunk log entries already overwritten (ring)");
+    uint32_t n = st.n_chunks - first;
     if (n > cap) n = (uint32_t)cap;
-    if (n && out5) HIPCHK(hipMemcpy(out5, st.chunk_log, sizeof(double) * 5 * n, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < n; ++k)
+        HIPCHK(hipMemcpy(out5 + 5 * (size_t)k, st.chunk_log + 5 * (size_t)((first + k) % st.cap_chunks), sizeof(double) * 5,
+                         hipMemcpyDeviceToHost));
     return (long)n;
 }
 

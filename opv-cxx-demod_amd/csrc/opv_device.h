@@ -37,8 +37,10 @@ struct OpvStream {
     uint64_t n_avail;    // samples available behind iq
     int32_t eof;         // no more samples will arrive
     int32_t pad0;
-    double* soft;        // soft-symbol log
-    uint64_t cap_soft;
+    double* soft;        // soft-symbol log: a ring, symbol number i lives at soft[i & (cap_soft-1)]
+    uint64_t cap_soft;   // power of two, > everything one opv_process can produce + one frame
+    uint64_t iq_base;    // absolute index of iq[0] (bookkeeping; kernels index relative to iq)
+    uint32_t frames_popped, events_popped;  // consumer cursors: frame/event records are rings
     OpvFrameRec* frec;   // frame records
     OpvEventRec* events;
     double* chunk_log;   // 5 doubles per demodulate() call

@@ -81,7 +81,7 @@ void print_frame(int num, const uint8_t* f, int metric, double sync) {  // ref :
 
 struct Options {
     bool quiet = false, raw = false, coherent = false, streaming = false, have_off = false;
-    double afc = 0.001, off = 0.0, capacity_sec = 120.0;
+    double afc = 0.001, off = 0.0, capacity_sec = 2.0;
     int device = 0;
 };
 
@@ -133,8 +133,10 @@ struct Sink {
             all_meta.insert(all_meta.end(), meta.begin(), meta.begin() + n);
             if (n < 256) break;
         }
-        std::vector<double> cl((size_t)st.n_chunks * 5);
-        if (st.n_chunks && opv_tap_chunks(ctx, 0, cl.data(), st.n_chunks) < 0) return -1;
+        const size_t n_new = (size_t)st.n_chunks - chunks_seen;  // chunk log entries not printed yet
+        std::vector<double> cl(n_new * 5 + 5);
+        if (n_new && opv_tap_chunks(ctx, 0, (uint32_t)chunks_seen, cl.data(), n_new) < 0) return -1;
+        const size_t chunk0 = chunks_seen;
 
         size_t ie = 0, ifr = 0;
         auto emit_until = [&](uint64_t sym_end) {  // everything with symbol index < sym_end
@@ -156,7 +158,7 @@ struct Sink {
             }
         };
         for (; chunks_seen < (size_t)st.n_chunks; ++chunks_seen) {
-            const double* c = &cl[chunks_seen * 5];
+            const double* c = &cl[(chunks_seen - chunk0) * 5];
             const uint64_t nsym = (uint64_t)c[4];
             // chunk size = what demodulate() was given: full chunks are 86720, the tail is the rest
             emit_until(total_symbols + nsym);
@@ -206,7 +208,7 @@ int main(int argc, char** argv) {
             fprintf(stderr, "  -o <hz>     Initial frequency offset (streaming mode)\n");
             fprintf(stderr, "  -p <hz>     PLL bandwidth (coherent only; ignored)\n");
             fprintf(stderr, "  --device <n>        HIP device ordinal (default 0)\n");
-            fprintf(stderr, "  --capacity-sec <s>  streaming capture capacity in seconds of IQ (default 120)\n");
+            fprintf(stderr, "  --capacity-sec <s>  device staging buffer in seconds of IQ (default 2; streams may be any length)\n");
             fprintf(stderr, "  -h          Help\n");
             return 0;
         }

@@ -102,7 +102,7 @@ def lib():
         L.opv_tap_soft.restype = C.c_long
         L.opv_tap_soft.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_size_t]
         L.opv_tap_chunks.restype = C.c_long
-        L.opv_tap_chunks.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.opv_tap_chunks.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
         L.opv_tap_offset_energies.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.opv_decode_payloads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
@@ -219,10 +219,10 @@ class Demod:
         n = _chk(lib().opv_tap_soft(self.h, stream, first, out.ctypes.data, cap))
         return out[:n].copy()
 
-    def chunks(self, stream):
+    def chunks(self, stream, first=0):
         cap = int(self.cfg.max_samples) // 80000 + 4
         out = np.zeros((cap, 5), np.float64)
-        n = _chk(lib().opv_tap_chunks(self.h, stream, out.ctypes.data, cap))
+        n = _chk(lib().opv_tap_chunks(self.h, stream, first, out.ctypes.data, cap))
         return out[:n].copy()
 
     def offset_energies(self, stream):

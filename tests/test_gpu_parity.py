@@ -284,3 +284,50 @@ def test_64_streams_device_channel_round_trip(amd, oracle):
         check_stream(amd, got, exp, f"device-channel stream {k}")
         d2.close()
     d.close()
+
+
+def test_long_stream_through_a_small_device_buffer(amd, oracle, iq100):
+    """opv-modem keeps one demodulator alive for hours: a pushed stream may be far longer than the
+    device buffers (opv_cfg.max_samples). 100 frames (8.7 M samples) through a 3-chunk buffer in
+    16 KB pushes: consumed IQ / soft symbols are dropped on the fly, record rings wrap, and the
+    frames, metrics, sync positions and tracker lines still equal the oracle's."""
+    x = impair(iq100, amp=2500.0, f0_hz=-900.0, ebn0_db=13.0, seed=21)
+    exp = oracle.receive(x, streaming=True)
+    cap = 3 * 86720 + 8192
+    d = amd.Demod(1, max_samples=cap, streaming=True)
+    frames, metas, events = [], [], []
+    step = 2 * 4096
+    for o in range(0, x.size, step):
+        d.push(0, x[o:o + step])
+        d.process()
+        f, m = d.pop_frames(0)
+        frames.append(f)
+        metas.append(m)
+        events.append(d.pop_events(0))
+    d.flush(0)
+    d.process()
+    f, m = d.pop_frames(0)
+    frames.append(f)
+    metas.append(m)
+    events.append(d.pop_events(0))
+    frames, metas, events = np.concatenate(frames), np.concatenate(metas), np.concatenate(events)
+    assert len(frames) == len(exp["frames"]) > 90
+    assert np.array_equal(frames, exp["frames"])
+    assert np.array_equal(metas["viterbi_metric"], exp["metrics"])
+    assert np.array_equal(metas["release_symbol"], exp["frame_sym"])
+    assert amd.format_events(events) == format_events(exp["events"])
+    st = d.state(0)
+    assert st.total_symbols == exp["n_soft"] and st.n_chunks == len(exp["chunks"])
+    assert st.frames_decoded == len(exp["frames"])
+    assert abs(st.freq_offset_hz - exp["final_freq_offset"]) < 1e-6
+    tail = d.soft(0, first=exp["n_soft"] - 1000)
+    a, _ = soft_err(tail, exp["soft"][-1000:])
+    assert a < SOFT_TIGHT
+    with pytest.raises(amd.OpvError):
+        d.soft(0, first=0)                     # long gone
+    d.close()
+    # a push that cannot fit even after dropping everything consumed is refused loudly
+    d = amd.Demod(1, max_samples=100000, streaming=True)
+    with pytest.raises(amd.OpvError):
+        d.push(0, x[: 2 * 150000])
+    d.close()
