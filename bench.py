@@ -9,8 +9,8 @@ tracker -> frame decode) over one batch of synthetic captures that are ALREADY R
 Per GPU the batch is BASELINE.json configs[3]: 64 independent IQ streams x 1000 frames
 (86 724 000 samples each, 2.168 MSPS), `-s` semantics; with N GPUs that is configs[4] shape
 (64 streams per GPU, weak scaling), decoded frames gathered to rank 0 with one RCCL gather.
-Stream k is the host-generated BERT capture (bit-identical to `opv-mod -S W5NYV -B 1000`)
-passed through the device channel tool: amplitude 2000, carrier offset f0_k = -1500 + 3000 k/63
+Stream k is its own BERT capture generated in HBM by the device modulator (bit-identical to what
+`opv-mod -S S<k> -B 1000` would emit) and passed through the device channel tool: amplitude 2000, carrier offset f0_k = -1500 + 3000 k/63
 Hz, AWGN at Eb/N0 = 16 dB. Every step is checked: all 64 x 1000 decoded
 frames must equal the transmitted ones (a full-size encode -> channel -> decode round trip).
 
@@ -107,33 +107,37 @@ def main():
     amd.lib()
     S, F = args.streams, args.frames
 
-    # ---- synthetic input: host modulator -> HBM -> device channel tool ----------------------
-    tx_frames = amd.bert_frames(F)
-    t0 = time.perf_counter()
-    base = amd.modulate(tx_frames)                       # int16 IQ, bit-identical to opv-mod
-    t_mod = time.perf_counter() - t0
-    n = base.size // 2
+    # ---- synthetic input, generated IN HBM: device modulator (bit-identical to `opv-mod`, see
+    # tests) -> device channel tool. Every stream carries its own BERT payload sequence.
+    n = amd.lib().opv_tx_modulated_samples(F)
     assert n % 4 == 0
-    d_base = torch.from_numpy(base).to(dev)
+    d_clean = torch.empty(2 * n, dtype=torch.int16, device=dev)
     d_iq = torch.empty((S, 2 * n), dtype=torch.int16, device=dev)
     dm = amd.Demod(S, max_samples=n + 64, streaming=True, device=local_rank)
     amp = 2000.0
     sigma = 0.0
     if args.ebn0 > 0:
         sigma = float(np.sqrt(80.0 * amp * amp / 10.0 ** (args.ebn0 / 10.0) / 2.0))
+    tx_all = np.empty((S, F, 134), np.uint8)
+    t_mod = 0.0
     for k in range(S):
         gk = rank * S + k
+        tx_all[k] = amd.bert_frames(F, callsign=f"S{gk}", first=1000 * gk)
+        t0 = time.perf_counter()
+        dm.modulate_device(tx_all[k], d_clean.data_ptr())
+        t_mod += time.perf_counter() - t0
         f0 = -1500.0 + 3000.0 * (gk % 64) / 63.0
-        dm.channel(d_base.data_ptr(), d_iq[k].data_ptr(), n, gain=amp / 16383.0, f0_hz=f0, sigma=sigma,
+        dm.channel(d_clean.data_ptr(), d_iq[k].data_ptr(), n, gain=amp / 16383.0, f0_hz=f0, sigma=sigma,
                    seed=1000 + gk)
     dm.sync()
     torch.cuda.synchronize()
+    tx_frames = amd.bert_frames(F)                       # configs[1] / CPU-baseline capture (W5NYV)
 
     fptr, mptr, cptr, fcap = dm.device_frames()
     frames_view = torch.as_tensor(DevPtr(fptr, (S, fcap, 134), "|u1"), device=dev)
     counts_view = torch.as_tensor(DevPtr(cptr, (S,), "<i4"), device=dev)
     gathered = [torch.empty_like(frames_view) for _ in range(world)] if (world > 1 and rank == 0) else None
-    expect = torch.from_numpy(tx_frames).to(dev)
+    expect = torch.from_numpy(tx_all).to(dev)
 
     stats = {}
 
@@ -150,7 +154,7 @@ def main():
             # (at 16 dB a handful of frames carry residual channel errors) >= 99% of them must
             # equal the transmitted bytes; clean runs (--ebn0 0) must be 100% exact.
             cnt = counts_view.cpu().numpy()
-            neq = (frames_view[:, :F, :] != expect.unsqueeze(0)).any(dim=2)
+            neq = (frames_view[:, :F, :] != expect).any(dim=2)
             n_bad = int(neq.sum().item())
             stats["frames_total"] = int(S * F)
             stats["frames_exact"] = int(S * F - n_bad)
@@ -186,7 +190,12 @@ def main():
         if rank == 0:
             g = torch.stack(gathered)                    # [world, S, fcap, 134] in global stream order
             assert bool((g[0] == frames_view).all().item()), "gathered frames of rank 0 differ from the local ones"
-            stats["gathered_frames_exact"] = int((g[:, :, :F, :] == expect.view(1, 1, F, 134)).all(dim=3).sum().item())
+            exp_all = np.stack([np.stack([amd.bert_frames(F, callsign=f"S{r * S + k}", first=1000 * (r * S + k))
+                                          for k in range(S)]) for r in range(world)])
+            same = (g[:, :, :F, :].cpu().numpy() == exp_all).all(axis=3)
+            stats["gathered_frames_total"] = int(same.size)
+            stats["gathered_frames_exact"] = int(same.sum())
+            assert same.mean() > 0.99, "frames gathered from the other ranks do not match what they were sent"
 
     total_samples = float(world) * S * n * args.steps
     msps = total_samples / dt / 1e6
@@ -234,6 +243,11 @@ def main():
         extras = {}
         # configs[1]: one clean 1000-frame stream
         one = amd.Demod(1, max_samples=n + 64, streaming=True, device=local_rank)
+        d_base = torch.empty(2 * n, dtype=torch.int16, device=dev)
+        t0 = time.perf_counter()
+        one.modulate_device(tx_frames, d_base.data_ptr())
+        one.sync()
+        t_dev_mod = time.perf_counter() - t0
         for rep in range(2):
             one.reset()
             one.attach(0, d_base.data_ptr(), n, eof=True)
@@ -274,8 +288,11 @@ def main():
             m.close()
         extras["stream_sweep"] = sweep
         out["extras"] = extras
+        base = d_base.cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(base.tobytes(), n)
-        out["setup"] = {"host_modulate_s": round(t_mod, 2)}
+        out["setup"] = {"device_modulate_s_all_streams": round(t_mod, 2),
+                        "device_modulate_one_stream": {"s": round(t_dev_mod, 3), "Msamples/s": round(n / t_dev_mod / 1e6, 1),
+                                                        "note": "opv_tx_modulate_device incl. host bit-level pass + H2D of codes"}}
     elif rank == 0:
         out["cpu_baseline"] = None
 

@@ -178,6 +178,12 @@ int opv_decode_payloads(opv_ctx* ctx, const double* soft, size_t n_frames, uint8
 void opv_tx_bert_frame(const char* callsign, uint32_t token, uint32_t frame_num, uint8_t out134[OPV_FRAME_BYTES]);
 size_t opv_tx_modulated_samples(size_t n_frames);
 size_t opv_tx_modulate(const uint8_t* frames134, size_t n_frames, int16_t* iq_out);
+/* Device-side modulator: same result as opv_tx_modulate, written straight
+ * into HBM (d_iq_out: device pointer, 16-byte aligned, opv_tx_modulated_samples(n_frames) samples).
+ * Bit-level work stays on the host; samples whose truncation could differ between device sincos
+ * and libm are re-evaluated on the host. Returns the number of samples so patched (>= 0, normally
+ * 0) or a negative error. */
+long opv_tx_modulate_device(opv_ctx* ctx, const uint8_t* frames134, size_t n_frames, int16_t* d_iq_out);
 /* Device-side channel tool for synthetic multi-stream workloads:
  * d_out[n] = clip(rint(gain * d_in[n] * exp(j 2 pi f0 n / Fs) + sigma * N(0,1)+jN(0,1))),
  * noise from a counter-based generator keyed by (seed, n). d_in/d_out: device int16 IQ. */

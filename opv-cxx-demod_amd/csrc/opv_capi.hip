@@ -15,6 +15,7 @@
 
 #include "../../include/opv_demod.h"
 #include "opv_device.h"
+#include "opv_tx_internal.h"
 
 extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg);
 extern "C" __global__ void k_msk_frontend(OpvStream*, OpvGlobalCfg);
@@ -22,6 +23,7 @@ extern "C" __global__ void k_sync_track(OpvStream*);
 extern "C" __global__ void k_frame_decode(OpvStream*);
 extern "C" __global__ void k_decode_payloads(const double*, uint32_t, uint8_t*, int32_t*, int8_t*, int8_t*, uint8_t*);
 extern "C" __global__ void k_channel(const int4*, int4*, uint64_t, double, double, double, uint64_t);
+extern "C" __global__ void k_tx_modulate(const int8_t*, const double2*, uint64_t, int*, uint32_t*, uint64_t*, uint32_t);
 
 namespace {
 
@@ -109,6 +111,11 @@ struct opv_ctx {
     uint64_t cap_soft = 0;
     uint32_t cap_frames = 0, cap_events = 0, cap_chunks = 0;
     bool mirror_valid = false;
+    // device modulator cache: NCO phases at symbol starts (data-independent, grown on demand)
+    std::vector<double> tx_phases;       // host copy, 2 doubles per symbol
+    double tx_ph1 = 0.0, tx_ph2 = 0.0;   // phases after the last cached symbol
+    double* d_tx_phases = nullptr;
+    size_t d_tx_phases_cap = 0;          // symbols
     bool timing = false;
     bool timing_valid = false;
     hipEvent_t ev[8] = {};
@@ -210,7 +217,7 @@ extern "C" void opv_destroy(opv_ctx* c) {
         if (h.d_iq_owned) (void)hipFree(h.d_iq_owned);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_counts};
+    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_counts, c->d_tx_phases};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -575,4 +582,63 @@ extern "C" int opv_channel_device(opv_ctx* c, const int16_t* d_in, int16_t* d_ou
     k_channel<<<blocks, 256, 0, c->stream>>>((const int4*)d_in, (int4*)d_out, quads, gain, f0_hz / 2168000.0, sigma, seed);
     HIPCHK(hipGetLastError());
     return OPV_OK;
+}
+
+extern "C" long opv_tx_modulate_device(opv_ctx* c, const uint8_t* frames, size_t n_frames, int16_t* d_iq_out) {
+    if (!c || !d_iq_out || (!frames && n_frames)) return fail(OPV_EINVAL, "null argument");
+    if (((uintptr_t)d_iq_out & 15u) != 0) return fail(OPV_EINVAL, "device IQ pointer must be 16-byte aligned");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t nsym = n_frames * OPV_FSYMS, nsym_total = nsym + 100;  // + 100 silent symbols (opv-mod.cpp:528-529)
+    // symbol-start phases: extend the cache with the reference's own accumulation, upload once
+    if (c->tx_phases.size() < 2 * nsym) {
+        const size_t have = c->tx_phases.size() / 2;
+        c->tx_phases.resize(2 * nsym);
+        opv_tx_symbol_phases(have, nsym - have, &c->tx_ph1, &c->tx_ph2, c->tx_phases.data() + 2 * have);
+    }
+    if (c->d_tx_phases_cap < nsym) {
+        if (c->d_tx_phases) HIPCHK(hipFree(c->d_tx_phases));
+        c->d_tx_phases = nullptr;
+        c->d_tx_phases_cap = 0;
+        if (nsym) HIPCHK(hipMalloc(&c->d_tx_phases, sizeof(double) * 2 * nsym));
+        c->d_tx_phases_cap = nsym;
+        if (nsym) HIPCHK(hipMemcpy(c->d_tx_phases, c->tx_phases.data(), sizeof(double) * 2 * nsym, hipMemcpyHostToDevice));
+    }
+    std::vector<int8_t> amp(nsym_total, 0);
+    opv_tx_symbol_codes(frames, n_frames, amp.data());
+    int8_t* d_amp = nullptr;
+    uint32_t* d_cnt = nullptr;
+    uint64_t* d_list = nullptr;
+    constexpr uint32_t kAmbCap = 4096;
+    int rc = OPV_OK;
+    auto chk = [&](hipError_t e, const char* w) { if (e != hipSuccess && rc == OPV_OK) rc = fail(OPV_EHIP, w, e); };
+    chk(hipMalloc(&d_amp, nsym_total), "hipMalloc amp");
+    chk(hipMalloc(&d_cnt, sizeof(uint32_t)), "hipMalloc amb_count");
+    chk(hipMalloc(&d_list, sizeof(uint64_t) * kAmbCap), "hipMalloc amb_list");
+    long patched = 0;
+    if (rc == OPV_OK) {
+        chk(hipMemcpyAsync(d_amp, amp.data(), nsym_total, hipMemcpyHostToDevice, c->stream), "H2D amp");
+        chk(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), c->stream), "memset");
+        const unsigned blocks = (unsigned)((nsym_total + 63) / 64);
+        k_tx_modulate<<<blocks, 64, 0, c->stream>>>(d_amp, (const double2*)c->d_tx_phases, nsym_total, (int*)d_iq_out,
+                                                    d_cnt, d_list, kAmbCap);
+        chk(hipGetLastError(), "k_tx_modulate launch");
+        uint32_t n_amb = 0;
+        chk(hipMemcpyAsync(&n_amb, d_cnt, sizeof n_amb, hipMemcpyDeviceToHost, c->stream), "D2H count");
+        chk(hipStreamSynchronize(c->stream), "sync");
+        if (rc == OPV_OK && n_amb > kAmbCap) rc = fail(OPV_ECAPACITY, "too many ambiguous samples (internal)");
+        if (rc == OPV_OK && n_amb) {  // re-evaluate with libm exactly like the reference
+            std::vector<uint64_t> list(n_amb);
+            chk(hipMemcpy(list.data(), d_list, sizeof(uint64_t) * n_amb, hipMemcpyDeviceToHost), "D2H list");
+            for (uint64_t n : list) {
+                const size_t sym = n / OPV_SPS;
+                int16_t iq[2];
+                opv_tx_sample_exact(c->tx_phases[2 * sym], c->tx_phases[2 * sym + 1], amp[sym], (int)(n % OPV_SPS), &iq[0], &iq[1]);
+                chk(hipMemcpy(d_iq_out + 2 * n, iq, 4, hipMemcpyHostToDevice), "H2D patch");
+            }
+            patched = (long)n_amb;
+        }
+    }
+    void* ptrs[] = {d_amp, d_cnt, d_list};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    return rc == OPV_OK ? patched : rc;
 }

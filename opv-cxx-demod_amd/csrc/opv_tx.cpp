@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/opv_demod.h"
+#include "opv_tx_internal.h"
 
 namespace {
 
@@ -108,28 +109,60 @@ extern "C" size_t opv_tx_modulated_samples(size_t n_frames) {
     return n_frames * (size_t)OPV_FRAME_SYMBOLS * kSps + 100u * kSps;
 }
 
+// ---- pieces shared with the device modulator (opv_tx_internal.h) ----------------------------
+void opv_tx_symbol_codes(const uint8_t* frames, size_t n_frames, int8_t* amp) {
+    std::vector<uint8_t> sym(OPV_FRAME_SYMBOLS);
+    int T = 0, bn = 1;  // opv-mod.cpp:221-226: one modulator reset per run
+    for (size_t f = 0; f < n_frames; ++f) {
+        frame_symbols(frames + f * OPV_FRAME_BYTES, sym.data());
+        for (int k = 0; k < OPV_FRAME_SYMBOLS; ++k) {
+            const int d = sym[k] ? -1 : 1;
+            int a;
+            if (d == 1) a = T;                                  // tone 1, sign T (0 right after reset)
+            else a = 2 * ((bn == 0) ? -T : T);                  // tone 2, sign +/-T by symbol parity
+            amp[f * OPV_FRAME_SYMBOLS + k] = (int8_t)a;
+            T = (T == 0) ? 1 : d * T;
+            bn ^= 1;
+        }
+    }
+}
+
+void opv_tx_symbol_phases(size_t first_symbol, size_t n_symbols, double* ph1_io, double* ph2_io, double* out2) {
+    // free-running NCOs, the reference's repeated addition + wrap (opv-mod.cpp:274-279); data-independent
+    const double inc1 = kTwoPi * (-kDev) / kFs, inc2 = kTwoPi * (+kDev) / kFs;
+    double ph1 = *ph1_io, ph2 = *ph2_io;
+    (void)first_symbol;
+    for (size_t k = 0; k < n_symbols; ++k) {
+        out2[2 * k] = ph1;
+        out2[2 * k + 1] = ph2;
+        for (int i = 0; i < kSps; ++i) { advance(ph1, inc1); advance(ph2, inc2); }
+    }
+    *ph1_io = ph1;
+    *ph2_io = ph2;
+}
+
+void opv_tx_sample_exact(double ph1_sym, double ph2_sym, int a, int i, int16_t* I, int16_t* Q) {
+    const double inc1 = kTwoPi * (-kDev) / kFs, inc2 = kTwoPi * (+kDev) / kFs;
+    double ph1 = ph1_sym, ph2 = ph2_sym;
+    for (int k = 0; k < i; ++k) { advance(ph1, inc1); advance(ph2, inc2); }
+    double vi = 0.0, vq = 0.0;
+    if (a == 1 || a == -1) { vi = a * std::sin(ph1); vq = a * std::cos(ph1); }
+    else if (a == 2 || a == -2) { const int sg = a / 2; vi = sg * std::sin(ph2); vq = sg * std::cos(ph2); }
+    *I = (int16_t)(16383.0 * vi);
+    *Q = (int16_t)(16383.0 * vq);
+}
+
 extern "C" size_t opv_tx_modulate(const uint8_t* frames, size_t n_frames, int16_t* iq) {
     const size_t nsym = n_frames * OPV_FRAME_SYMBOLS;
     // pass 1 (sequential, cheap): per-symbol active tone + sign, NCO phases at frame starts
     std::vector<int8_t> amp(nsym);  // +/-1: tone 1 active with that sign; +/-2: tone 2; 0: silent
     std::vector<FrameStart> fs(n_frames);
+    opv_tx_symbol_codes(frames, n_frames, amp.data());
     {
-        std::vector<uint8_t> sym(OPV_FRAME_SYMBOLS);
-        int T = 0, bn = 1;  // opv-mod.cpp:221-226
         double ph1 = 0.0, ph2 = 0.0;
         const double inc1 = kTwoPi * (-kDev) / kFs, inc2 = kTwoPi * (+kDev) / kFs;
         for (size_t f = 0; f < n_frames; ++f) {
             fs[f] = {ph1, ph2};
-            frame_symbols(frames + f * OPV_FRAME_BYTES, sym.data());
-            for (int k = 0; k < OPV_FRAME_SYMBOLS; ++k) {
-                const int d = sym[k] ? -1 : 1;
-                int a;
-                if (d == 1) a = T;                                  // tone 1, sign T (0 right after reset)
-                else a = 2 * ((bn == 0) ? -T : T);                  // tone 2, sign +/-T by symbol parity
-                amp[f * OPV_FRAME_SYMBOLS + k] = (int8_t)a;
-                T = (T == 0) ? 1 : d * T;
-                bn ^= 1;
-            }
             for (int k = 0; k < OPV_FRAME_SYMBOLS * kSps; ++k) { advance(ph1, inc1); advance(ph2, inc2); }
         }
     }

@@ -31,7 +31,7 @@ EXPORTS = [
     "opv_attach_device_iq", "opv_process", "opv_sync", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_tap_soft", "opv_tap_chunks",
     "opv_tap_offset_energies", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_modulated_samples",
-    "opv_tx_modulate", "opv_channel_device", "opv_enable_timing", "opv_kernel_times",
+    "opv_tx_modulate", "opv_channel_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device",
 ]
 
 
@@ -79,6 +79,14 @@ def lib():
     if _lib is None:
         if not LIB_PATH.exists():
             raise OpvError(f"{LIB_PATH} is missing: run `make -C {PKG}` (there is no CPU fallback)")
+        # PyTorch-ROCm wheels bundle their own libamdhip64.so.7. Two HIP runtimes in one process do not
+        # work ("No HIP GPUs are available" in whichever initialises second), and the dynamic loader
+        # keys on the soname: whichever copy is loaded first serves both. When torch is present, let
+        # it load first so that this library binds to the runtime torch was built for.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(str(LIB_PATH))
         L.opv_last_error.restype = C.c_char_p
         L.opv_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(Cfg)]
@@ -115,6 +123,8 @@ def lib():
         L.opv_channel_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double,
                                          C.c_double, C.c_uint64]
         L.opv_enable_timing.argtypes = [C.c_void_p, C.c_int]
+        L.opv_tx_modulate_device.restype = C.c_long
+        L.opv_tx_modulate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.opv_kernel_times.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -250,6 +260,11 @@ class Demod:
 
     def hip_stream(self):
         return lib().opv_hip_stream(self.h)
+
+    def modulate_device(self, frames, d_out):
+        """TX chain into HBM (bit-identical to modulate()); returns samples re-evaluated on the host."""
+        frames = np.ascontiguousarray(frames, np.uint8).reshape(-1, FRAME_BYTES)
+        return _chk(lib().opv_tx_modulate_device(self.h, frames.ctypes.data, len(frames), C.c_void_p(d_out)))
 
     def channel(self, d_in, d_out, n_samples, gain=1.0, f0_hz=0.0, sigma=0.0, seed=0):
         _chk(lib().opv_channel_device(self.h, C.c_void_p(d_in), C.c_void_p(d_out), n_samples, gain, f0_hz, sigma,

@@ -331,3 +331,25 @@ def test_long_stream_through_a_small_device_buffer(amd, oracle, iq100):
     with pytest.raises(amd.OpvError):
         d.push(0, x[: 2 * 150000])
     d.close()
+
+
+def test_device_modulator_is_bit_identical_to_host_and_reference(amd, golden):
+    """the TX chain writing straight into HBM. Same bytes as the host
+    modulator, hence (sha256 pins) as the reference `opv-mod`."""
+    import torch
+    _, meta = golden
+    pins = meta["opv_mod_bert_W5NYV"]
+    d = amd.Demod(1, max_samples=1 << 20)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    for frames, pin in ((amd.bert_frames(10), pins["10"]["sha256"]), (amd.bert_frames(100), pins["100"]["sha256"]),
+                        (rng.integers(0, 256, (7, 134), dtype=np.uint8), None), (np.zeros((0, 134), np.uint8), None)):
+        n = amd.lib().opv_tx_modulated_samples(len(frames))
+        out = torch.empty(2 * n, dtype=torch.int16, device=dev)
+        patched = d.modulate_device(frames, out.data_ptr())
+        got = out.cpu().numpy()
+        assert np.array_equal(got, amd.modulate(frames)), f"{len(frames)} frames, {patched} patched"
+        if pin:
+            assert hashlib.sha256(got.tobytes()).hexdigest() == pin
+        print(len(frames), "frames: host-patched samples:", patched)
+    d.close()
