@@ -403,6 +403,15 @@ extern "C" int opv_kernel_times(opv_ctx* c, float ms[4]) {
     return OPV_OK;
 }
 
+// copies records [first, first+n) of a device ring with `cap` slots of `elem` bytes into dst (host)
+static int ring_to_host(void* dst, const void* d_ring, uint32_t first, uint32_t n, uint32_t cap, size_t elem) {
+    const uint32_t p0 = first % cap;
+    const uint32_t run = n < cap - p0 ? n : cap - p0;
+    HIPCHK(hipMemcpy(dst, (const char*)d_ring + (size_t)p0 * elem, (size_t)run * elem, hipMemcpyDeviceToHost));
+    if (run < n) HIPCHK(hipMemcpy((char*)dst + (size_t)run * elem, d_ring, (size_t)(n - run) * elem, hipMemcpyDeviceToHost));
+    return OPV_OK;
+}
+
 extern "C" long opv_pop_frames(opv_ctx* c, int s, uint8_t* out, size_t cap, opv_frame_meta* meta) {
     if (int r = check_stream(c, s)) return r;
     if (int r = c->refresh()) return r;
@@ -411,30 +420,42 @@ extern "C" long opv_pop_frames(opv_ctx* c, int s, uint8_t* out, size_t cap, opv_
     HostStream& h = c->hs[s];
     const uint32_t nf = st.n_frames;
     if (h.popped >= nf || cap == 0) return 0;
+    // candidates: at most `cap` decodable frames can be returned, dropped ones are skipped, so look at
+    // the unread records in slices of up to cap and stop when the caller's buffer is full
     size_t w = 0;
     uint32_t f = h.popped;
-    for (; f < nf && w < cap; ++f) {
-        const uint32_t slot = f % st.cap_frames;  // records are rings
-        int32_t met;
-        HIPCHK(hipMemcpy(&met, st.metrics + slot, sizeof met, hipMemcpyDeviceToHost));
-        if (met == INT32_MIN) break;              // released but not decoded yet (cannot happen after opv_process)
-        if (met < 0) continue;                    // dropped silent frame (ref :859, :1052)
-        OpvFrameRec rec;
-        HIPCHK(hipMemcpy(&rec, st.frec + slot, sizeof rec, hipMemcpyDeviceToHost));
-        if (out) HIPCHK(hipMemcpy(out + w * OPV_FB, st.frames + (size_t)slot * OPV_FB, OPV_FB, hipMemcpyDeviceToHost));
-        if (meta) {
-            meta[w].viterbi_metric = met;
-            meta[w].reserved = 0;
-            meta[w].sync_quality = rec.quality;
-            meta[w].release_symbol = rec.release_sym;
-            meta[w].payload_symbol = rec.payload_sym;
+    std::vector<int32_t> met;
+    std::vector<OpvFrameRec> rec;
+    std::vector<uint8_t> fr;
+    while (f < nf && w < cap) {
+        uint32_t n = nf - f;
+        if (n > cap - w) n = (uint32_t)(cap - w);
+        if (n > st.cap_frames) n = st.cap_frames;
+        met.resize(n);
+        rec.resize(n);
+        fr.resize((size_t)n * OPV_FB);
+        if (int r = ring_to_host(met.data(), st.metrics, f, n, st.cap_frames, sizeof(int32_t))) return r;
+        if (int r = ring_to_host(rec.data(), st.frec, f, n, st.cap_frames, sizeof(OpvFrameRec))) return r;
+        if (int r = ring_to_host(fr.data(), st.frames, f, n, st.cap_frames, OPV_FB)) return r;
+        bool stop = false;
+        for (uint32_t k = 0; k < n; ++k, ++f) {
+            if (met[k] == INT32_MIN) { stop = true; break; }  // released but not decoded yet (cannot happen after opv_process)
+            if (met[k] < 0) continue;                         // dropped silent frame (ref :859, :1052)
+            if (out) std::memcpy(out + w * OPV_FB, fr.data() + (size_t)k * OPV_FB, OPV_FB);
+            if (meta) {
+                meta[w].viterbi_metric = met[k];
+                meta[w].reserved = 0;
+                meta[w].sync_quality = rec[k].quality;
+                meta[w].release_symbol = rec[k].release_sym;
+                meta[w].payload_symbol = rec[k].payload_sym;
+            }
+            ++h.decoded;
+            if (met[k] == 0) ++h.perfect;
+            ++w;
         }
-        ++h.decoded;
-        if (met == 0) ++h.perfect;
-        ++w;
+        if (stop) break;
     }
     h.popped = f;
-    h.dirty = h.dirty;  // cursors travel with the next opv_process
     return (long)w;
 }
 
@@ -448,10 +469,7 @@ extern "C" long opv_pop_events(opv_ctx* c, int s, opv_event* out, size_t cap) {
     uint32_t n = ne - h.events_popped;
     if (n > cap) n = (uint32_t)cap;
     static_assert(sizeof(opv_event) == sizeof(OpvEventRec), "event layouts must match");
-    const uint32_t first = h.events_popped % st.cap_events;
-    const uint32_t run = n < st.cap_events - first ? n : st.cap_events - first;  // up to the ring's end
-    HIPCHK(hipMemcpy(out, st.events + first, sizeof(OpvEventRec) * run, hipMemcpyDeviceToHost));
-    if (run < n) HIPCHK(hipMemcpy(out + run, st.events, sizeof(OpvEventRec) * (n - run), hipMemcpyDeviceToHost));
+    if (int r = ring_to_host(out, st.events, h.events_popped, n, st.cap_events, sizeof(OpvEventRec))) return r;
     h.events_popped += n;
     return (long)n;
 }
@@ -476,10 +494,13 @@ extern "C" int opv_get_state(opv_ctx* c, int s, opv_stream_state* out) {
     const HostStream& h = c->hs[s];
     out->frames_decoded = h.decoded;
     out->frames_perfect = h.perfect;
-    for (uint32_t f = h.popped; f < st.n_frames; ++f) {  // released but not popped yet
-        int32_t m;
-        HIPCHK(hipMemcpy(&m, st.metrics + (f % st.cap_frames), sizeof m, hipMemcpyDeviceToHost));
-        if (m >= 0) { out->frames_decoded++; if (m == 0) out->frames_perfect++; }
+    if (st.n_frames > h.popped) {  // released but not popped yet
+        uint32_t n = st.n_frames - h.popped;
+        if (n > st.cap_frames) n = st.cap_frames;
+        std::vector<int32_t> met(n);
+        if (int r = ring_to_host(met.data(), st.metrics, h.popped, n, st.cap_frames, sizeof(int32_t))) return r;
+        for (int32_t m : met)
+            if (m >= 0) { out->frames_decoded++; if (m == 0) out->frames_perfect++; }
     }
     return st.overflow ? fail(OPV_ECAPACITY, "a device log overflowed") : OPV_OK;
 }
