@@ -353,3 +353,48 @@ def test_device_modulator_is_bit_identical_to_host_and_reference(amd, golden):
             assert hashlib.sha256(got.tobytes()).hexdigest() == pin
         print(len(frames), "frames: host-patched samples:", patched)
     d.close()
+
+
+def test_batch_mode_100_frames_noisy(amd, oracle, iq100):
+    """Batch mode = ONE demodulate() over the whole capture (reference :1173): pos runs to 8.7e6
+    (fp64 resolution of the sample position matters there) and there are no chunk artefacts."""
+    x = impair(iq100, amp=3000.0, f0_hz=1100.0, ebn0_db=11.0, seed=9)
+    d = amd.Demod(1, max_samples=x.size // 2 + 64, streaming=False)
+    got = d.receive([x])[0]
+    check_stream(amd, got, oracle.receive(x, streaming=False), "batch 100 frames 11 dB")
+    d.close()
+
+
+def test_reset_and_reuse_and_two_contexts(amd, oracle, iq10):
+    x = impair(iq10, amp=2000.0, f0_hz=300.0, ebn0_db=15.0, seed=4)
+    exp = oracle.receive(x, streaming=True)
+    a = amd.Demod(2, max_samples=x.size // 2 + 64, streaming=True)
+    b = amd.Demod(1, max_samples=x.size // 2 + 64, streaming=True)
+    for rep in range(2):
+        got = a.receive([x, iq10])
+        check_stream(amd, got[0], exp, f"ctx a rep {rep}")
+        gb = b.receive([x])[0]
+        check_stream(amd, gb, exp, f"ctx b rep {rep}")
+        a.reset()
+        b.reset(0)
+    a.close()
+    b.close()
+
+
+def test_growing_attached_capture(amd, oracle, iq10):
+    """Zero-copy path fed incrementally: the caller's HBM buffer grows (eof=False), then ends."""
+    import torch
+    dev = torch.device("cuda", 0)
+    d_x = torch.from_numpy(iq10).to(dev)
+    n = iq10.size // 2
+    d = amd.Demod(1, max_samples=n + 64, streaming=True)
+    for upto in (50000, 86720, 300000, 300001, n - 7, n):
+        d.attach(0, d_x.data_ptr(), upto, eof=(upto == n))
+        d.process()
+    d.sync()
+    fr, meta = d.pop_frames(0)
+    exp = oracle.receive(iq10, streaming=True)
+    assert np.array_equal(fr, exp["frames"]) and np.array_equal(meta["release_symbol"], exp["frame_sym"])
+    a, _ = soft_err(d.soft(0), exp["soft"])
+    assert a < SOFT_TIGHT
+    d.close()
