@@ -301,7 +301,7 @@ extern "C" int opv_flush(opv_ctx* c, int s) {
 extern "C" int opv_attach_device_iq(opv_ctx* c, int s, const int16_t* d_iq, size_t n, int eof) {
     if (int r = check_stream(c, s)) return r;
     HostStream& h = c->hs[s];
-    if (h.d_iq_owned) return fail(OPV_ESTATE, "stream already has pushed samples");
+    if (h.d_iq_owned && h.n_avail && !h.attached) return fail(OPV_ESTATE, "stream already has pushed samples (reset it first)");
     if (!d_iq && n) return fail(OPV_EINVAL, "null device pointer");
     if (((uintptr_t)d_iq & 15u) != 0) return fail(OPV_EINVAL, "device IQ pointer must be 16-byte aligned");
     if (n > c->cfg.max_samples) return fail(OPV_ECAPACITY, "opv_cfg.max_samples exceeded");
@@ -486,7 +486,7 @@ extern "C" int opv_get_state(opv_ctx* c, int s, opv_stream_state* out) {
     out->mu = st.mu;
     out->total_symbols = st.n_soft;
     out->total_samples = st.total_samples;
-    out->chunk_origin = st.origin;
+    out->chunk_origin = st.origin + st.iq_base;  // absolute sample index
     out->sync_state = st.trk_state;
     out->frames_released = (int32_t)st.n_frames;
     out->n_chunks = (int32_t)st.n_chunks;
