@@ -1,0 +1,149 @@
+// opv_rx_bridge.cpp — multi-stream receive bridge: N IQ byte streams -> ONE GPU context -> UDP.
+//
+// The MI355X-side counterpart of the reference modem's RX mode (`opv-modem -R`, reference
+// src/opv-modem.cpp:673-838: stdin IQ -> `opv-demod -s -r` child -> 134-byte UDP datagrams to
+// port 57373). Instead of one child process per stream it drives the C ABI
+// directly: every input is a stream of one opv_ctx, fed in the reference's 16 KB reads
+// (opv-modem.cpp:734,753), and each decoded frame leaves as one datagram, exactly 134 bytes
+// (opv-modem.cpp:782-783). Stream k sends to UDP port base+k. The demodulator's inherent
+// one-frame latency (a frame is released once 50 samples of the next one have arrived,
+// src/opv-demod.cpp:221) is unchanged.
+//
+//   opv-rx-bridge [-H host] [-P base_port] [-o hz] [-a alpha] [--device n] [-q] [input ...]
+//     inputs: files or FIFOs with int16 I/Q; none = stdin as the only stream.
+#include <arpa/inet.h>
+#include <fcntl.h>
+#include <netinet/in.h>
+#include <poll.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/opv_demod.h"
+
+namespace {
+struct Input {
+    int fd = -1;
+    bool eof = false;
+    unsigned char carry[4];
+    size_t ncarry = 0;
+    long frames = 0, perfect = 0;
+    uint64_t samples = 0;
+};
+}  // namespace
+
+int main(int argc, char** argv) {
+    std::string host = "127.0.0.1";
+    int base_port = 57373;  // OPV network port (opv-modem.cpp:567-568)
+    bool quiet = false, have_off = false;
+    double off = 0.0, afc = 0.001;
+    int device = 0;
+    std::vector<std::string> paths;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "-H") && i + 1 < argc) host = argv[++i];
+        else if (!strcmp(argv[i], "-P") && i + 1 < argc) base_port = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-o") && i + 1 < argc) { off = atof(argv[++i]); have_off = true; }
+        else if (!strcmp(argv[i], "-a") && i + 1 < argc) afc = atof(argv[++i]);
+        else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "-q")) quiet = true;
+        else if (!strcmp(argv[i], "-h")) {
+            fprintf(stderr, "Usage: %s [-H host] [-P base_port] [-o hz] [-a alpha] [--device n] [-q] [input ...]\n", argv[0]);
+            return 0;
+        } else paths.push_back(argv[i]);
+    }
+    const int S = paths.empty() ? 1 : (int)paths.size();
+    std::vector<Input> in(S);
+    for (int k = 0; k < S; ++k) {
+        in[k].fd = paths.empty() ? STDIN_FILENO : open(paths[k].c_str(), O_RDONLY | O_NONBLOCK);
+        if (in[k].fd < 0) { perror(paths[k].c_str()); return 2; }
+        fcntl(in[k].fd, F_SETFL, fcntl(in[k].fd, F_GETFL) | O_NONBLOCK);
+    }
+    const int sock = socket(AF_INET, SOCK_DGRAM, 0);
+    if (sock < 0) { perror("socket"); return 2; }
+    std::vector<sockaddr_in> dst(S);
+    for (int k = 0; k < S; ++k) {
+        memset(&dst[k], 0, sizeof dst[k]);
+        dst[k].sin_family = AF_INET;
+        dst[k].sin_port = htons((uint16_t)(base_port + k));
+        if (inet_pton(AF_INET, host.c_str(), &dst[k].sin_addr) != 1) { fprintf(stderr, "bad host %s\n", host.c_str()); return 2; }
+    }
+
+    opv_cfg cfg{};
+    cfg.streaming = 1;
+    cfg.have_init_offset = have_off;
+    cfg.init_offset_hz = off;
+    cfg.afc_alpha = afc;
+    cfg.device = device;
+    cfg.max_samples = 8 * OPV_CHUNK_SAMPLES;  // staging buffer per stream; streams themselves are unbounded
+    opv_ctx* ctx = nullptr;
+    if (opv_create(&ctx, S, &cfg) < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
+    if (!quiet) fprintf(stderr, "opv-rx-bridge: %d stream(s) -> udp://%s:%d..%d\n", S, host.c_str(), base_port, base_port + S - 1);
+
+    std::vector<pollfd> pfd(S);
+    std::vector<unsigned char> buf(16384 + 4);
+    uint8_t frames[64 * OPV_FRAME_BYTES];
+    opv_frame_meta meta[64];
+    int open_streams = S;
+    auto drain = [&]() -> int {
+        if (opv_process(ctx) < 0) return -1;
+        for (int k = 0; k < S; ++k) {
+            for (;;) {
+                const long n = opv_pop_frames(ctx, k, frames, 64, meta);
+                if (n < 0) return -1;
+                for (long f = 0; f < n; ++f) {
+                    sendto(sock, frames + f * OPV_FRAME_BYTES, OPV_FRAME_BYTES, 0, (sockaddr*)&dst[k], sizeof dst[k]);
+                    in[k].frames++;
+                    if (meta[f].viterbi_metric == 0) in[k].perfect++;
+                }
+                if (n < 64) break;
+            }
+        }
+        return 0;
+    };
+    while (open_streams > 0) {
+        for (int k = 0; k < S; ++k) { pfd[k].fd = in[k].eof ? -1 : in[k].fd; pfd[k].events = POLLIN; pfd[k].revents = 0; }
+        if (poll(pfd.data(), S, 10) < 0) break;  // 10 ms like the reference's select timeout
+        bool any = false;
+        for (int k = 0; k < S; ++k) {
+            if (in[k].eof) continue;
+            if (!(pfd[k].revents & (POLLIN | POLLHUP))) continue;
+            memcpy(buf.data(), in[k].carry, in[k].ncarry);
+            const ssize_t r = read(in[k].fd, buf.data() + in[k].ncarry, 16384);
+            if (r < 0) continue;  // EAGAIN
+            if (r == 0) {
+                in[k].eof = true;
+                --open_streams;
+                if (opv_flush(ctx, k) < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
+                any = true;
+                continue;
+            }
+            const size_t have = in[k].ncarry + (size_t)r, ns = have / 4;
+            if (ns && opv_push_iq(ctx, k, reinterpret_cast<const int16_t*>(buf.data()), ns) < 0) {
+                fprintf(stderr, "opv-rx-bridge: stream %d: %s\n", k, opv_last_error());
+                return 2;
+            }
+            in[k].samples += ns;
+            in[k].ncarry = have - ns * 4;
+            memcpy(in[k].carry, buf.data() + ns * 4, in[k].ncarry);
+            any = true;
+        }
+        if (any && drain() < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
+    }
+    if (drain() < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
+    long total = 0;
+    for (int k = 0; k < S; ++k) {
+        total += in[k].frames;
+        if (!quiet)
+            fprintf(stderr, "stream %d: %.3f s of IQ, %ld frames (%ld perfect) -> port %d\n", k, in[k].samples / 2168000.0,
+                    in[k].frames, in[k].perfect, base_port + k);
+    }
+    opv_destroy(ctx);
+    close(sock);
+    return total > 0 ? 0 : 1;
+}

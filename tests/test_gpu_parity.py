@@ -6,6 +6,7 @@ soft symbols within 1e-5 relative (north_star) — we assert a much tighter 1e-9
 scale-normalised error and report the measured value.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -453,3 +454,42 @@ def test_config2_full_size_offset_awgn(amd, oracle, f0, ebn0):
     print(f"soft max|d|/mean = {a:.2e}, max rel = {r:.2e}")
     assert a < SOFT_TIGHT and r < SOFT_RTOL
     d.close()
+
+
+def test_rx_bridge_multi_stream_udp(amd, oracle, tmp_path):
+    """the caller side of the boundary. Three IQ files -> opv-rx-bridge (one GPU
+    context, 16 KB reads like opv-modem) -> 134-byte UDP datagrams on ports base+k; every stream's
+    datagrams must be the oracle's frames, in order."""
+    import socket
+    import subprocess
+    base = 40000 + (os.getpid() % 2000) * 4
+    socks = []
+    for k in range(3):
+        so = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        so.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1 << 22)
+        so.bind(("127.0.0.1", base + k))
+        so.setblocking(False)
+        socks.append(so)
+    caps, exps = [], []
+    for k in range(3):
+        x = oracle.modulate(oracle.bert_frames(12 + 3 * k, f"K{k}XYZ", 0xBBAADD, 50 * k))
+        if k == 2:
+            x = impair(x, amp=2500.0, f0_hz=800.0, ebn0_db=14.0, seed=k)
+        f = tmp_path / f"s{k}.iq"
+        x.tofile(f)
+        caps.append(str(f))
+        exps.append(oracle.receive(x, streaming=True)["frames"])
+    exe = str(amd.PKG / "bin" / "opv-rx-bridge")
+    r = subprocess.run([exe, "-P", str(base)] + caps, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    for k in range(3):
+        got = []
+        while True:
+            try:
+                got.append(socks[k].recv(2048))
+            except BlockingIOError:
+                break
+        assert all(len(g) == FRAME_BYTES for g in got)
+        got = np.frombuffer(b"".join(got), np.uint8).reshape(-1, FRAME_BYTES)
+        assert np.array_equal(got, exps[k]), f"stream {k}: {len(got)} datagrams vs {len(exps[k])} frames"
+        socks[k].close()
