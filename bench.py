@@ -99,9 +99,13 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # OPV_BENCH_FORCE_DIST=1 runs the N>1 code path (RCCL init, gather of the frame buffer, MAX over
+    # ranks) even with one rank: a self-test of that path on boxes with a single GPU.
+    use_dist = world > 1 or os.environ.get("OPV_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     amd = load_amd()
     amd.lib()
@@ -136,7 +140,7 @@ def main():
     fptr, mptr, cptr, fcap = dm.device_frames()
     frames_view = torch.as_tensor(DevPtr(fptr, (S, fcap, 134), "|u1"), device=dev)
     counts_view = torch.as_tensor(DevPtr(cptr, (S,), "<i4"), device=dev)
-    gathered = [torch.empty_like(frames_view) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty_like(frames_view) for _ in range(world)] if (use_dist and rank == 0) else None
     expect = torch.from_numpy(tx_all).to(dev)
 
     stats = {}
@@ -147,7 +151,7 @@ def main():
             dm.attach(k, d_iq[k].data_ptr(), n, eof=True)
         dm.process()
         dm.sync()
-        if world > 1:
+        if use_dist:
             dist.gather(frames_view, gathered, dst=0)    # RCCL over xGMI: frames back to rank 0
         if check:
             # full-size round trip: every stream must release exactly F frames, in order, and
@@ -167,7 +171,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -183,7 +187,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     step(check=True)                                      # untimed: the timed configuration decodes correctly
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -299,7 +303,7 @@ def main():
     dm.close()
     if rank == 0:
         print(json.dumps(out, ensure_ascii=False))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
