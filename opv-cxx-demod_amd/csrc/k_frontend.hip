@@ -139,10 +139,10 @@ namespace {
 // copy of the table at a per-lane (identical) address, selects replace the quadrant branches.
 // r = min/max has already been formed by the caller (its divide runs beside the TED's divide).
 __device__ inline double atan_from_ratio(double r, double y, double x, const double* tab_lds) {
-    int k = (int)(r * 32.0);
-    k = k > 31 ? 31 : k;
-    const double ck = k ? ((double)k + 0.5) * (1.0 / 32.0) : 0.0;   // interval 0 is expanded at 0
-    const double h = r - ck;
+    const double kf = fmin(floor(r * 32.0), 31.0);                  // interval index, as a double
+    const int k = (int)kf;
+    // interval 0 is expanded at 0 (odd series), the others at their centre (k + 0.5)/32
+    const double h = r - (k ? fma(kf, 1.0 / 32.0, 1.0 / 64.0) : 0.0);
     const double2* t = reinterpret_cast<const double2*>(tab_lds + k * 10);
     const double2 c01 = t[0], c23 = t[1], c45 = t[2], c67 = t[3], c89 = t[4];
     double p = fma3(c89.y, h, c89.x);
@@ -187,7 +187,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
     // ---- carry ---------------------------------------------------------------------------
     double fo = st.freq_offset, tf = st.timing_freq, mu = st.mu;
     const double afc_gain = st.afc_alpha * (kSymRate / kTwoPi);  // ref :300-302
-    double q1r = st.p1r, q1i = st.p1i, q2r = st.p2r, q2i = st.p2i;   // previous on-time S_1, S_2
+    double qA = st.p1r, qB = st.p1i, qC = st.p2r, qD = st.p2i;       // previous on-time P1..P4 (S_1 = (A+B, C-D), S_2 = (A-B, C+D))
     double x40c_prev = st.x40c, x40s_prev = st.x40s;                 // X[40] of that symbol
     double fo_sum = st.fo_sum;
     uint32_t origin = uni((uint32_t)st.origin);
@@ -395,8 +395,9 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             // phase detector operands: dom * conj(prev) (ref :299). prev of the reference = S_prev
             // advanced by one symbol of LO rotation, (-/+ j) X40_prev; applied to the product:
             //   z = (S conj(S_prev)) * conj(X40_prev) * (+/- j)
-            const double dr = dom1 ? s1r_ : s2r_, di = dom1 ? s1i_ : s2i_;
-            const double pr = dom1 ? q1r : q2r, pi = dom1 ? q1i : q2i;   // previous S of that tone
+            // dominant tone's S = (P1 +/- P2, P3 -/+ P4), now and one symbol ago (same sign flip)
+            const double dr = P1o + flip(P2o), di = P3o - flip(P4o);
+            const double pr = qA + flip(qB), pi = qC - flip(qD);         // previous S of that tone
             const double ar = dr * pr + di * pi, ai = di * pr - dr * pi;
             const double ur = fma(ar, x40c_prev, ai * x40s_prev);
             const double ui = fma(ai, x40c_prev, -(ar * x40s_prev));
@@ -459,7 +460,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 fo = clampd(fma(afc_gain, pdz, fo_used), -2000.0, 2000.0);
             }
             // prev <- this symbol's on-time correlations and LO rotation (ref :309-310)
-            q1r = s1r_; q1i = s1i_; q2r = s2r_; q2i = s2i_;
+            qA = P1o; qB = P2o; qC = P3o; qD = P4o;
             x40c_prev = x40c; x40s_prev = x40s;
             fo_sum += fo_used;
             delta = fo * kDeltaPerHz;
@@ -489,7 +490,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
 
     if (lane == 0) {
         st.freq_offset = fo; st.timing_freq = tf; st.mu = mu;
-        st.p1r = q1r; st.p1i = q1i; st.p2r = q2r; st.p2i = q2i; st.x40c = x40c_prev; st.x40s = x40s_prev;
+        st.p1r = qA; st.p1i = qB; st.p2r = qC; st.p2i = qD; st.x40c = x40c_prev; st.x40s = x40s_prev;
         st.fo_sum = fo_sum;
         st.origin = origin; st.n_soft = n_soft; st.total_samples = total_samples;
         st.n_chunks = n_chunks; st.tail_done = tail_done; st.overflow = overflow;

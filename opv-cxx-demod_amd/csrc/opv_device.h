@@ -53,7 +53,8 @@ struct OpvStream {
     double mu;
     double timing_freq;
     double afc_alpha;
-    // previous on-time correlations S_1, S_2 in the kernel's de-rotated form, and X[40] =
+    // previous on-time sums P1..P4 (S_1 = (P1+P2, P3-P4), S_2 = (P1-P2, P3+P4)) in the kernel's
+    // de-rotated form, stored in p1r,p1i,p2r,p2i in that order, and X[40] =
     // exp(j 40 d) of that symbol (the LO advance the reference's prev_corr implies; see
     // k_msk_frontend)
     double p1r, p1i, p2r, p2i;
