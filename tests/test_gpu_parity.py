@@ -493,3 +493,34 @@ def test_rx_bridge_multi_stream_udp(amd, oracle, tmp_path):
         got = np.frombuffer(b"".join(got), np.uint8).reshape(-1, FRAME_BYTES)
         assert np.array_equal(got, exps[k]), f"stream {k}: {len(got)} datagrams vs {len(exps[k])} frames"
         socks[k].close()
+
+
+def test_config3_full_size_sampled_streams(amd, oracle):
+    """BASELINE configs[3] at full size for a sample of its streams: 1000 frames each, generated exactly
+    like bench.py does (device modulator, per-stream payload, f0 from -1500..+1500 Hz, 16 dB). Four
+    streams run concurrently in one context and each must equal the oracle run on the same IQ."""
+    import torch
+    F, ks = 1000, (0, 21, 42, 63)
+    dev = torch.device("cuda", 0)
+    n = amd.lib().opv_tx_modulated_samples(F)
+    d = amd.Demod(len(ks), max_samples=n + 64, streaming=True)
+    clean = torch.empty(2 * n, dtype=torch.int16, device=dev)
+    iq = torch.empty((len(ks), 2 * n), dtype=torch.int16, device=dev)
+    sigma = float(np.sqrt(80.0 * 2000.0 ** 2 / 10.0 ** 1.6 / 2.0))
+    for j, k in enumerate(ks):
+        d.modulate_device(amd.bert_frames(F, callsign=f"S{k}", first=1000 * k), clean.data_ptr())
+        d.channel(clean.data_ptr(), iq[j].data_ptr(), n, gain=2000.0 / 16383.0, f0_hz=-1500.0 + 3000.0 * k / 63.0,
+                  sigma=sigma, seed=1000 + k)
+    d.sync()
+    for j in range(len(ks)):
+        d.attach(j, iq[j].data_ptr(), n, eof=True)
+    d.process()
+    for j, k in enumerate(ks):
+        fr, meta = d.pop_frames(j)
+        exp = oracle.receive(iq[j].cpu().numpy(), streaming=True, want_soft=False)
+        assert len(fr) == 1000 and np.array_equal(fr, exp["frames"]), k
+        assert np.array_equal(meta["viterbi_metric"], exp["metrics"]), k
+        assert np.array_equal(meta["release_symbol"], exp["frame_sym"]), k
+        events_match(amd, d.pop_events(j), exp["events"])
+        assert abs(d.state(j).freq_offset_hz - exp["final_freq_offset"]) < 1e-6
+    d.close()
