@@ -53,10 +53,6 @@
 
 #include "opv_device.h"
 
-#ifndef OPV_ABLATE
-#define OPV_ABLATE 0  // timing experiments only; the product is always built with 0
-#endif
-
 namespace {
 
 constexpr double kPi = 3.14159265358979323846;  // ref :43
@@ -317,9 +313,6 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             // ---- X = exp(j kf delta) by Taylor (|x| <= 0.29) --------------------------------
             const double x = kf * delta;
             const double x2 = x * x;
-#if OPV_ABLATE == 5
-            const double xs = x, xc = 1.0 - 0.5 * x2;
-#else
             double sp = -1.0 / 39916800.0;                 // x^11
             sp = fma3(sp, x2, 1.0 / 362880.0);
             sp = fma3(sp, x2, -1.0 / 5040.0);
@@ -335,7 +328,6 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             cp = fma3(cp, x2, -0.5);
             const double xc = fma3(cp, x2, 1.0);           // cos
 
-#endif
             // Z = Lam * conj(X)
             const double zr = fma(lr, xc, li * xs);
             const double zi = fma(li, xc, -(lr * xs));
@@ -349,17 +341,10 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             const double r0 = swap32_add(v0, v6), r1 = swap32_add(v1, v7), r2 = swap32_add(v2, v8);
             const double r3 = swap32_add(v3, v9), r4 = swap32_add(v4, v10), r5 = swap32_add(v5, v11);
             double q0 = swap16_add(r0, r3), q1 = swap16_add(r1, r4), q2 = swap16_add(r2, r5);
-#if OPV_ABLATE != 4
             q0 = row_allsum(q0);
             q1 = row_allsum(q1);
             q2 = row_allsum(q2);
-#endif
             // row 0: P1{E,O,L}  row 1: P2  row 2: P3  row 3: P4
-#if OPV_ABLATE == 2
-            const double x40c = readlane_d(xc, 50), x40s = readlane_d(xs, 50);
-            const double P1e = q0, P1o = q1, P1l = q2, P2e = q0 * 0.5, P2o = q1 * 0.25, P2l = q2 * 0.5;
-            const double P3e = q0 * 0.125, P3o = q1 * 0.5, P3l = q2 * 0.25, P4e = q0 * 0.75, P4o = q1 * 0.75, P4l = q2 * 0.125;
-#else
             if ((lane & 15) == 0) {
                 double* d = red + (lane >> 4) * 3;
                 d[0] = q0; d[1] = q1; d[2] = q2;
@@ -371,8 +356,6 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             const double P3e = red[6], P3o = red[7], P3l = red[8];
             const double P4e = red[9], P4o = red[10], P4l = red[11];
             __builtin_amdgcn_wave_barrier();
-
-#endif
 
             // ---- uniform tail (all lanes, identical). Deliberately free of branches up to the
             // fetch of the next symbol: the timing chain (TED divide -> loop filter -> pos) and the

@@ -16,7 +16,7 @@ from pathlib import Path
 import numpy as np
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = Path(__import__("os").environ.get("OPV_AMD_LIB", PKG / "libopv_demod_hip.so"))  # override: timing experiments only
+LIB_PATH = PKG / "libopv_demod_hip.so"
 
 SPS = 40
 FRAME_BYTES = 134

@@ -1,5 +1,5 @@
 #!/bin/bash
-# scratch: PMC passes on the front-end kernel
+# dev helper: PMC passes on the front-end kernel (run through scripts/gpurun_retry.sh)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc

@@ -1,5 +1,5 @@
 #!/bin/bash
-# scratch: parity + a short bench (invoked through gpurun)
+# dev helper: GPU parity tests + a short bench (run through scripts/gpurun_retry.sh)
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -4
 timeout 600 python bench.py --streams 64 --frames 100 --steps 2 --warmup 1 --no-extras 2>&1 | grep -v amdgpu.ids | python -c "
