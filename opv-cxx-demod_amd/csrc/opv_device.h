@@ -14,8 +14,8 @@
 #define OPV_CHUNK 86720
 #define OPV_SYNC_WORD 0x02B8DBu
 
-#define OPV_TILE_SAMPLES 2168                 // HBM->LDS staging unit: one frame tile of int16 IQ
-#define OPV_TILE_BYTES (OPV_TILE_SAMPLES * 4) // 8672 B = 542 x 16 B
+#define OPV_TILE_SAMPLES 2048                 // HBM->LDS staging unit of int16 IQ (two tiles = a power-of-two ring)
+#define OPV_TILE_BYTES (OPV_TILE_SAMPLES * 4) // 8192 B = 8 wave-wide 16 B/lane loads
 
 struct OpvFrameRec {       // written by k_sync_track, read by k_frame_decode and the host
     uint64_t payload_sym;  // index of first payload soft symbol in the soft log
