@@ -80,9 +80,9 @@ static_assert((kRing & (kRing - 1)) == 0, "ring must be a power of two");
 // atan table (32 rows x 12 doubles: c0..c9, interval centre, pad)
 constexpr uint32_t kRedOff = kRingBytes + kGuardBytes;   // 16400
 constexpr uint32_t kSinkOff = kRedOff + 96;              // 16496
-constexpr uint32_t kTabOff = kSinkOff + 64 * 8 + 16;     // 17024
+constexpr uint32_t kTabOff = kSinkOff + 64 * 8 + 80;     // 17088
 constexpr uint32_t kTabRow = 12;
-constexpr uint32_t kLdsBytes = kTabOff + 32 * kTabRow * 8;  // 20096 <= 20480: eight workgroups per CU
+constexpr uint32_t kLdsBytes = kTabOff + 32 * kTabRow * 8;  // 20160 <= 20480: eight workgroups per CU
 static_assert(kTabOff % 16 == 0 && kRedOff % 16 == 0, "16-byte LDS alignment");
 
 typedef __attribute__((address_space(1))) double gdouble;
@@ -126,6 +126,10 @@ __device__ inline double clampd(double v, double lo, double hi) { return fmin(fm
 // q, r near-minimax of degree 4 on u <= 0.0823 (mpmath chebyfit; abs error 1e-19 / 1.3e-18).
 // One asm block: the constants stay in registers as written and hipcc's hazard recogniser does
 // not pad between the dependent FMAs.
+struct PrevSums {
+    double a, b, c, d;  // on-time P1..P4
+    double x40c, x40s;  // X[40] = exp(j 40 d) of that symbol
+};
 struct SinCosK {
     double s0, s1, s2, s3, s4;  // q(u) low -> high
     double c0, c1, c2, c3, c4;  // r(u) low -> high
@@ -186,14 +190,13 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
     sck.c0 = -0x1.0000000000000p-1; sck.c1 = 0x1.5555555555014p-5; sck.c2 = -0x1.6c16c16818f3fp-10;
     sck.c3 = 0x1.a019dfaa26924p-16; sck.c4 = -0x1.276f06eab6283p-22;
     // where this lane parks its three row sums: row leaders in the scratch, the rest in a sink
-    double* const red_wr = reinterpret_cast<double*>(lds + ((lane & 15) == 0 ? kRedOff + (uint32_t)(lane >> 4) * 24u
+    double* const red_wr = reinterpret_cast<double*>(lds + ((lane & 15) == 0 ? kRedOff + (uint32_t)(lane >> 4) * 8u
                                                                               : kSinkOff + (uint32_t)lane * 8u));
 
     // ---- carry ---------------------------------------------------------------------------
     double fo = st.freq_offset, tf = st.timing_freq, mu = st.mu;
     const double afc_gain = st.afc_alpha * (kSymRate / kTwoPi);  // ref :300-302
-    double qA = st.p1r, qB = st.p1i, qC = st.p2r, qD = st.p2i;       // previous on-time P1..P4 (S_1 = (A+B, C-D), S_2 = (A-B, C+D))
-    double x40c_prev = st.x40c, x40s_prev = st.x40s;                 // X[40] of that symbol
+    PrevSums qp{st.p1r, st.p1i, st.p2r, st.p2i, st.x40c, st.x40s}, qq{0, 0, 0, 0, 1, 0};    // previous on-time P1..P4 (S_1 = (a+b, c-d), S_2 = (a-b, c+d))
     double fo_sum = st.fo_sum;
     uint32_t origin = uni((uint32_t)st.origin);
     const uint32_t n_avail = uni((uint32_t)st.n_avail);
@@ -323,9 +326,14 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             w1 = tap[1];
         };
 
-        // One symbol: correlate the fetched taps, run both loop filters, log the soft value.
-        // kFirst: first symbol of a demodulate() call, no AFC update (ref :289).
-        auto symbol = [&](auto first_tag) {
+        // One symbol: correlate the fetched taps, run both loop filters, log the soft value, fetch
+        // the next symbol's taps. kFirst: first symbol of a demodulate() call, no AFC update
+        // (ref :289). `cur` receives this symbol's on-time sums and X[40], `prv` holds the
+        // previous symbol's.
+        // The sched_barriers pin the order in which the wave issues the three LDS round trips so
+        // that each is covered by arithmetic that does not depend on it: scratch reads <- X[40]
+        // hand-over; atan table row <- the whole timing loop; next taps <- the atan polynomial.
+        auto symbol = [&](auto first_tag, PrevSums& cur, const PrevSums& prv) {
             constexpr bool kFirst = decltype(first_tag)::value;
             // ---- the lane's sample, LO factor and 12 partial products ----------------------------
             const int s0r = (int)(short)(w0 & 0xFFFF), s0i = w0 >> 16;      // ref :1023
@@ -356,13 +364,19 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             __builtin_amdgcn_sched_barrier(0);
             q0 = dpp_add<0x121>(q0); q1 = dpp_add<0x121>(q1); q2 = dpp_add<0x121>(q2);
             __builtin_amdgcn_sched_barrier(0);
-            // row 0: P1{E,O,L}  row 1: P2  row 2: P3  row 3: P4
-            red_wr[0] = q0; red_wr[1] = q1; red_wr[2] = q2;
+            // row r holds P_{r+1}{E,O,L}; scratch layout [O: P1..P4 | E: P1..P4 | L: P1..P4], the
+            // on-time sums first because the tail needs them first
+            red_wr[0] = q1; red_wr[4] = q0; red_wr[8] = q2;
             __builtin_amdgcn_wave_barrier();
-            const double P1e = red[0], P1o = red[1], P1l = red[2];
-            const double P2e = red[3], P2o = red[4], P2l = red[5];
-            const double P3e = red[6], P3o = red[7], P3l = red[8];
-            const double P4e = red[9], P4o = red[10], P4l = red[11];
+            const double P1o = red[0], P2o = red[1], P3o = red[2], P4o = red[3];
+            const double P1e = red[4], P2e = red[5], P3e = red[6], P4e = red[7];
+            const double P1l = red[8], P2l = red[9], P3l = red[10], P4l = red[11];
+            // in the shadow of that round trip: this symbol's X[40] for the next one (lane 50)
+            cur.x40c = readlane_d(xc, 50);
+            cur.x40s = readlane_d(xs, 50);
+            const uint32_t my_soft_off = soft_off;
+            soft_off = (soft_off + 8u) & soft_bmask;
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_wave_barrier();
 
             // ---- uniform tail (all lanes, identical) -------------------------------------------
@@ -374,13 +388,15 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             const bool dom1 = en2 < en1;                            // e1 > e2 (ref :272 / :291)
             // dominant tone of every gate: C = (P1 + sg P2, P3 - sg P4), sg = +1 tone 1, -1 tone 2
             const double sg = dom1 ? 1.0 : -1.0;
-            const double er = fma(sg, P2e, P1e), ei = fma(-sg, P4e, P3e);
-            const double lr2 = fma(sg, P2l, P1l), li2 = fma(-sg, P4l, P3l);
-            const double ee = fma(er, er, ei * ei), el = fma(lr2, lr2, li2 * li2);
-            const double num = el - ee, den = el + ee + 1e-10;      // ted = num/den (ref :275/:279)
-
-            double ted;
+            double ted, pd = 0.0;
+            [[maybe_unused]] double dr = 0, di = 0, cx = 0, cy = 0, ax = 0, ay = 0, mx = 1.0, ratio = 0;
+            [[maybe_unused]] double2 c01{0, 0}, c23{0, 0}, c45{0, 0}, c67{0, 0}, c89{0, 0};
+            [[maybe_unused]] double centre = 0;
             if constexpr (kFirst) {
+                const double er = fma(sg, P2e, P1e), ei = fma(-sg, P4e, P3e);
+                const double lr2 = fma(sg, P2l, P1l), li2 = fma(-sg, P4l, P3l);
+                const double ee = fma(er, er, ei * ei), el = fma(lr2, lr2, li2 * li2);
+                const double num = el - ee, den = el + ee + 1e-10;  // ted = num/den (ref :275/:279)
                 double y = __builtin_amdgcn_rcp(den);
                 y = fma(fma(-den, y, 1.0), y, y);
                 y = fma(fma(-den, y, 1.0), y, y);
@@ -392,34 +408,58 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 //   z = (S conj(S_prev)) * conj(X40_prev) * (+/- j)
                 // With the previous S scaled by sg (prs = sg pr, pis = sg pi) the (+/- j) becomes a
                 // fixed one: z = (cx, cy) below.
-                const double dr = fma(sg, P2o, P1o), di = fma(-sg, P4o, P3o);
-                const double prs = fma(sg, qA, qB), pis = fma(sg, qC, -qD);
+                dr = fma(sg, P2o, P1o); di = fma(-sg, P4o, P3o);
+                const double prs = fma(sg, prv.a, prv.b), pis = fma(sg, prv.c, -prv.d);
                 const double ar = fma(dr, prs, di * pis), ai = fma(di, prs, -(dr * pis));
-                const double cy = fma(ar, x40c_prev, ai * x40s_prev);      // Im z
-                const double cx = fma(ar, x40s_prev, -(ai * x40c_prev));   // Re z
-                const double ax = fabs(cx), ay = fabs(cy);
-                const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+                cy = fma(ar, prv.x40c, ai * prv.x40s);              // Im z
+                cx = fma(ar, prv.x40s, -(ai * prv.x40c));           // Re z
+                ax = fabs(cx); ay = fabs(cy);
+                mx = fmax(ax, ay);
+                const double mn = fmin(ax, ay);
+                const double er = fma(sg, P2e, P1e), ei = fma(-sg, P4e, P3e);
+                const double lr2 = fma(sg, P2l, P1l), li2 = fma(-sg, P4l, P3l);
+                const double ee = fma(er, er, ei * ei), el = fma(lr2, lr2, li2 * li2);
+                const double num = el - ee, den = el + ee + 1e-10;  // ted = num/den (ref :275/:279)
 
                 // the two divides of the symbol on one reciprocal: ted and mn/mx for the phase
                 // detector; den in [1e-10, 2e12], dm in [1e-100, 1e12]
-                const double dm = fmax(mx, 1e-100);                     // digital silence: 0/1e-100 = 0, fixed up below
+                const double dm = fmax(mx, 1e-100);                 // digital silence: 0/1e-100 = 0, fixed up below
                 const double tt = den * dm;
                 double y = __builtin_amdgcn_rcp(tt);
                 y = fma(fma(-tt, y, 1.0), y, y);
                 y = fma(fma(-tt, y, 1.0), y, y);
                 const double iden = y * dm, idm = y * den;
-                ted = num * iden;
-                ted = fma(fma(-den, ted, num), iden, ted);
-                double ratio = mn * idm;
+                ratio = mn * idm;
                 ratio = fma(fma(-dm, ratio, mn), idm, ratio);
-
-                // atan2(cy, cx): table row by interval of ratio, degree-9 Horner, octant fix-up
+                // atan2(cy, cx): table row by interval of ratio (the row's LDS latency is covered by
+                // the timing loop below)
                 int k = (int)(ratio * 32.0);
                 k = k > 31 ? 31 : k;
                 const double2* trow = reinterpret_cast<const double2*>(atab + k * (int)kTabRow);
-                const double2 c01 = trow[0], c23 = trow[1], c45 = trow[2], c67 = trow[3], c89 = trow[4];
-                const double h = ratio - atab[k * (int)kTabRow + 10];
-                double pd = fma(c89.y, h, c89.x);
+                c89 = trow[4]; c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
+                centre = atab[k * (int)kTabRow + 10];
+                ted = num * iden;
+                ted = fma(fma(-den, ted, num), iden, ted);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+
+            // ---- timing loop, soft log, next symbol's taps ------------------------------------------
+            tf = clampd(fma(0.00001, ted, tf), -0.1, 0.1);          // beta (ref :118,:283-284)
+            const double adj = clampd(fma(0.005, ted, tf), -2.0, 2.0);  // alpha (ref :117,:285-286)
+            pos += 40.0 + adj;                                      // ref :313
+            [[maybe_unused]] double h = 0;
+            if constexpr (!kFirst) {
+                h = ratio - centre;                                 // first use of the table row: its wait sits
+                asm volatile("" : "+v"(h));                         //   here, before the taps are requested
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            fetch(pos, false);                                      // pos >= 38 after any symbol
+            *(gdouble*)(soft_base + my_soft_off) = soft;            // all lanes, same value and address
+            __builtin_amdgcn_sched_barrier(0);
+
+            // ---- AFC ------------------------------------------------------------------------------
+            if constexpr (!kFirst) {
+                pd = fma(c89.y, h, c89.x);                          // degree-9 Horner
                 pd = fma(pd, h, c67.y);
                 pd = fma(pd, h, c67.x);
                 pd = fma(pd, h, c45.y);
@@ -428,7 +468,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 pd = fma(pd, h, c23.x);
                 pd = fma(pd, h, c01.y);
                 pd = fma(pd, h, c01.x);
-                pd = (ay > ax) ? 1.57079632679489661923 - pd : pd;
+                pd = (ay > ax) ? 1.57079632679489661923 - pd : pd;  // octant fix-up
                 pd = (cx < 0.0) ? 3.14159265358979323846 - pd : pd;
                 pd = (cy < 0.0) ? -pd : pd;
 
@@ -444,11 +484,11 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                     // prev_t = P_t conj(E_t(k)), P_t = S_t(k-1) (-/+ j) X40(k-1),
                     // E_t(k) = exp(j(-/+ k pi/2 + (80 pi/Fs) sum_{j<k} fo_j)).
                     // Rare and wave-uniform; rebuilt here from the running sum of fo.
-                    const double pr = dom1 ? qA + qB : qA - qB, pi = dom1 ? qC - qD : qC + qD;
+                    const double pr = dom1 ? prv.a + prv.b : prv.a - prv.b, pi = dom1 ? prv.c - prv.d : prv.c + prv.d;
                     const bool dom_zero = (dr == 0.0 && di == 0.0), prev_zero = (pr == 0.0 && pi == 0.0);
                     pd = 0.0;
                     if (dom_zero != prev_zero) {
-                        const uint32_t nsym_call = ((soft_off - soft_off0) & soft_bmask) >> 3;
+                        const uint32_t nsym_call = ((my_soft_off - soft_off0) & soft_bmask) >> 3;
                         const uint64_t ksym = n_soft + nsym_call;       // symbols before this one
                         double th = (80.0 * kPi / kFs) * fo_sum;
                         th -= kTwoPi * rint(th / kTwoPi);
@@ -463,47 +503,39 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                         double vr = dr, vi = di;
                         if (dom_zero) {                                 // P = S_prev * (-/+ j) * X40_prev
                             const double jr = dom1 ? pi : -pi, ji = dom1 ? -pr : pr;
-                            vr = jr * x40c_prev - ji * x40s_prev;
-                            vi = jr * x40s_prev + ji * x40c_prev;
+                            vr = jr * prv.x40c - ji * prv.x40s;
+                            vi = jr * prv.x40s + ji * prv.x40c;
                         }
                         const double qr = vr * er2 + vi * ei2;          // v * conj(E)
                         const double qi = vi * er2 - vr * ei2;
                         if (qr < 0.0 && qi < 0.0) pd = kPi;
                     }
                 }
-                fo_sum += fo;                                           // sum of the fo every symbol USED
-                fo = clampd(fma(afc_gain, pd, fo), -2000.0, 2000.0);    // ref :300-303
             }
-            if constexpr (kFirst) fo_sum += fo;
-
-            tf = clampd(fma(0.00001, ted, tf), -0.1, 0.1);          // beta (ref :118,:283-284)
-            const double adj = clampd(fma(0.005, ted, tf), -2.0, 2.0);  // alpha (ref :117,:285-286)
-            pos += 40.0 + adj;                                      // ref :313
-
-            // prev <- this symbol's on-time correlations and LO rotation (ref :309-310)
-            qA = P1o; qB = P2o; qC = P3o; qD = P4o;
-            x40c_prev = readlane_d(xc, 50);                         // X[40] lives in lane 50
-            x40s_prev = readlane_d(xs, 50);
-
-            *(gdouble*)(soft_base + soft_off) = soft;               // all lanes, same value and address
-            soft_off = (soft_off + 8u) & soft_bmask;
+            fo_sum += fo;                                           // sum of the fo every symbol USED
+            if constexpr (!kFirst) fo = clampd(fma(afc_gain, pd, fo), -2000.0, 2000.0);  // ref :300-303
+            // prev <- this symbol's on-time correlations (ref :309-310)
+            cur.a = P1o; cur.b = P2o; cur.c = P3o; cur.d = P4o;
         };
 
         if (uni_lt(pos + 40.0 + 10.0, Nd)) {               // ref :221
             (void)housekeeping(pos);
             fetch(pos, true);
-            symbol(std::true_type{});
+            symbol(std::true_type{}, qp, qp);
             // Batches: the end-of-call test and the tile events once, then as many symbols as are
-            // provably clear of both, each fetching the next one's taps; the last of the batch
-            // leaves that fetch to the next round of bookkeeping.
+            // provably clear of both. Every symbol fetches its successor's taps; across a batch
+            // boundary that fetch is speculative (LDS only, harmless) and is repeated after the
+            // bookkeeping. Symbols go in pairs so that the "previous correlation" registers
+            // alternate instead of being copied.
             while (uni_lt(pos + 40.0 + 10.0, Nd)) {        // ref :221
-                uint32_t more = uni(housekeeping(pos));
-                fetch(pos, false);                         // pos >= 38 from the second symbol on
-                for (; more != 0u; --more) {
-                    symbol(std::false_type{});
-                    fetch(pos, false);
+                uint32_t pairs = uni(housekeeping(pos)) >> 1;
+                fetch(pos, false);
+                for (; pairs != 0u; --pairs) {
+                    symbol(std::false_type{}, qq, qp);
+                    symbol(std::false_type{}, qp, qq);
                 }
-                symbol(std::false_type{});
+                symbol(std::false_type{}, qq, qp);
+                qp = qq;
             }
         }
 
@@ -525,7 +557,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
 
     if (lane == 0) {
         st.freq_offset = fo; st.timing_freq = tf; st.mu = mu;
-        st.p1r = qA; st.p1i = qB; st.p2r = qC; st.p2i = qD; st.x40c = x40c_prev; st.x40s = x40s_prev;
+        st.p1r = qp.a; st.p1i = qp.b; st.p2r = qp.c; st.p2i = qp.d; st.x40c = qp.x40c; st.x40s = qp.x40s;
         st.fo_sum = fo_sum;
         st.origin = origin; st.n_soft = n_soft; st.total_samples = total_samples;
         st.n_chunks = n_chunks; st.tail_done = tail_done; st.overflow = overflow;

@@ -255,6 +255,121 @@ __global__ void k_global_store_lds(double* out, double* sink, int rep) {
     out[threadIdx.x] = p;
 }
 
+
+// ---- second batch: the instruction kinds of the front-end loop, one by one ----------------------
+__global__ void k_swap32_ind(double* out, int rep) {
+    int a = (int)out[threadIdx.x], b = a + 1, c = a + 2, d = a + 3;
+    for (int r = 0; r < rep; ++r) { asm volatile(U16("v_permlane32_swap_b32 %0, %1\nv_permlane32_swap_b32 %2, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+    out[threadIdx.x] = a + b + c + d;
+}
+__global__ void k_swap16_ind(double* out, int rep) {
+    int a = (int)out[threadIdx.x], b = a + 1, c = a + 2, d = a + 3;
+    for (int r = 0; r < rep; ++r) { asm volatile(U16("v_permlane16_swap_b32 %0, %1\nv_permlane16_swap_b32 %2, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+    out[threadIdx.x] = a + b + c + d;
+}
+__global__ void k_dppmov_ind(double* out, int rep) {
+    int a = (int)out[threadIdx.x], b, c, d, e;
+    for (int r = 0; r < rep; ++r) {
+        asm volatile(U16("v_mov_b32_dpp %1, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\nv_mov_b32_dpp %2, %0 row_ror:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                         "v_mov_b32_dpp %3, %0 row_ror:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\nv_mov_b32_dpp %4, %0 row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n")
+                     : "+v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e));
+    }
+    out[threadIdx.x] = a + b + c + d + e;
+}
+__global__ void k_mul_lo(double* out, int rep) {
+    int a = (int)out[threadIdx.x] + 3;
+    for (int r = 0; r < rep; ++r) { asm volatile(U64("v_mul_lo_u32 %0, %0, %0\n") : "+v"(a)); }
+    out[threadIdx.x] = a;
+}
+__global__ void k_mul_u24(double* out, int rep) {
+    int a = (int)out[threadIdx.x] + 3;
+    for (int r = 0; r < rep; ++r) { asm volatile(U64("v_mul_u32_u24 %0, %0, %0\n") : "+v"(a)); }
+    out[threadIdx.x] = a;
+}
+__global__ void k_ldexp(double* out, int rep) {
+    double a = out[threadIdx.x];
+    for (int r = 0; r < rep; ++r) { asm volatile(U64("v_ldexp_f64 %0, %0, 1\n") : "+v"(a)); }
+    out[threadIdx.x] = a;
+}
+__global__ void k_fract(double* out, int rep) {
+    double a = out[threadIdx.x];
+    for (int r = 0; r < rep; ++r) { asm volatile(U64("v_fract_f64 %0, %0\n") : "+v"(a)); }
+    out[threadIdx.x] = a;
+}
+__global__ void k_cvt_i32_f64(double* out, int rep) {
+    double a = out[threadIdx.x];
+    int i0, i1, i2, i3;
+    for (int r = 0; r < rep; ++r) { asm volatile(U16("v_cvt_i32_f64 %1, %0\nv_cvt_i32_f64 %2, %0\nv_cvt_i32_f64 %3, %0\nv_cvt_i32_f64 %4, %0\n") : "+v"(a), "=v"(i0), "=v"(i1), "=v"(i2), "=v"(i3)); }
+    out[threadIdx.x] = a + i0 + i1 + i2 + i3;
+}
+__global__ void k_cvt_f64_i32(double* out, int rep) {
+    int a = (int)out[threadIdx.x];
+    double d0, d1, d2, d3;
+    for (int r = 0; r < rep; ++r) { asm volatile(U16("v_cvt_f64_i32 %1, %0\nv_cvt_f64_i32 %2, %0\nv_cvt_f64_i32 %3, %0\nv_cvt_f64_i32 %4, %0\n") : "+v"(a), "=v"(d0), "=v"(d1), "=v"(d2), "=v"(d3)); }
+    out[threadIdx.x] = a + d0 + d1 + d2 + d3;
+}
+__global__ void k_mov_b64(double* out, int rep) {
+    double a = out[threadIdx.x], b;
+    for (int r = 0; r < rep; ++r) { asm volatile(U16("v_mov_b64 %1, %0\nv_mov_b64 %0, %1\nv_mov_b64 %1, %0\nv_mov_b64 %0, %1\n") : "+v"(a), "=&v"(b)); }
+    out[threadIdx.x] = a + b;
+}
+__global__ void k_cmp_cnd2(double* out, int rep) {
+    double a = out[threadIdx.x], b = 0.5;
+    int x = 1, y = 2;
+    unsigned long long m;
+    for (int r = 0; r < rep; ++r) {
+        asm volatile(U16("v_cmp_lt_f64 %3, %0, %1\nv_cndmask_b32 %2, %2, %4, %3\nv_cndmask_b32 %4, %4, %2, %3\n") : "+v"(a), "+v"(b), "+v"(x), "=&s"(m), "+v"(y));
+    }
+    out[threadIdx.x] = a + x + y;
+}
+// the broadcast round trip of the kernel: 2 writes, 6 x 16-byte reads, wait, dependent add
+__global__ void k_red_trip(double* out, int rep) {
+    __shared__ __attribute__((aligned(16))) double red[16];
+    double a = out[threadIdx.x];
+    const unsigned waddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)red + (threadIdx.x >> 4) * 24;
+    const unsigned raddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)red;
+    for (int r = 0; r < rep; ++r) {
+        double x0, x1, x2, x3, x4, x5, x6;
+        asm volatile(U16("ds_write2_b64 %7, %0, %0 offset1:1\nds_write_b64 %7, %0 offset:16\n"
+                         "ds_read_b64 %1, %8\nds_read_b64 %2, %8 offset:16\nds_read_b64 %3, %8 offset:32\nds_read_b64 %4, %8 offset:48\n"
+                         "ds_read_b64 %5, %8 offset:64\nds_read_b64 %6, %8 offset:80\ns_waitcnt lgkmcnt(0)\nv_add_f64 %0, %0, %6\n")
+                     : "+v"(a), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6) : "v"(waddr), "v"(raddr) : "memory");
+        (void)x0;
+    }
+    out[threadIdx.x] = a;
+}
+// 2 readlanes into SGPRs, then VALU consuming them (the X40 hand-over)
+__global__ void k_readlane_use(double* out, int rep) {
+    int a = (int)out[threadIdx.x], b = a + 1;
+    for (int r = 0; r < rep; ++r) {
+        int s0, s1;
+        asm volatile(U16("v_readlane_b32 %2, %0, 50\nv_readlane_b32 %3, %1, 50\ns_nop 0\nv_add_u32 %0, %0, %2\nv_add_u32 %1, %1, %3\n") : "+v"(a), "+v"(b), "=&s"(s0), "=&s"(s1));
+    }
+    out[threadIdx.x] = a + b;
+}
+// global store of one double per iteration with nothing else
+__global__ void k_gstore(double* out, double* sink, int rep) {
+    double v = 1.0;
+    unsigned off = 0;
+    for (int r = 0; r < rep; ++r) { asm volatile(U16("global_store_dwordx2 %0, %1, %2\n") : : "v"(off), "v"(v), "s"(sink) : "memory"); }
+    out[threadIdx.x] = v;
+}
+// s_waitcnt with nothing outstanding
+__global__ void k_waitcnt(double* out, int rep) {
+    for (int r = 0; r < rep; ++r) { asm volatile(U64("s_waitcnt lgkmcnt(0)\n") ::: "memory"); }
+    out[threadIdx.x] = rep;
+}
+__global__ void k_snop(double* out, int rep) {
+    for (int r = 0; r < rep; ++r) { asm volatile(U64("s_nop 0\n") ::: "memory"); }
+    out[threadIdx.x] = rep;
+}
+// alternating VALU / SALU (does the scalar instruction ride along for free?)
+__global__ void k_valu_salu(double* out, int rep) {
+    double a = out[threadIdx.x], b = 1.0000001, c = 1e-9;
+    int s = rep;
+    for (int r = 0; r < rep; ++r) { asm volatile(U64("v_fma_f64 %0, %0, %2, %3\ns_add_i32 %1, %1, 1\n") : "+v"(a), "+s"(s) : "v"(b), "v"(c) : "scc"); }
+    out[threadIdx.x] = a + s;
+}
 struct Test { const char* name; int per_rep; float ms; };
 
 int main() {
@@ -303,5 +418,22 @@ int main() {
     run("s_add dep", L1(k_salu), 64);
     run("flat st + lds chase", L2(k_flat_store_lds), 16);
     run("global st + lds chase", L2(k_global_store_lds), 16);
+    run("swap32 x2 indep", L1(k_swap32_ind), 16);
+    run("swap16 x2 indep", L1(k_swap16_ind), 16);
+    run("mov_dpp x4 indep", L1(k_dppmov_ind), 16);
+    run("mul_lo_u32 dep", L1(k_mul_lo), 64);
+    run("mul_u32_u24 dep", L1(k_mul_u24), 64);
+    run("ldexp_f64 dep", L1(k_ldexp), 64);
+    run("fract_f64 dep", L1(k_fract), 64);
+    run("cvt_i32_f64 x4", L1(k_cvt_i32_f64), 16);
+    run("cvt_f64_i32 x4", L1(k_cvt_f64_i32), 16);
+    run("mov_b64 x4 dep", L1(k_mov_b64), 16);
+    run("cmp_f64+2 cndmask", L1(k_cmp_cnd2), 16);
+    run("red trip 2w+6r+use", L1(k_red_trip), 16);
+    run("2 readlane+nop+2add", L1(k_readlane_use), 16);
+    run("global store", L2(k_gstore), 16);
+    run("s_waitcnt idle", L1(k_waitcnt), 64);
+    run("s_nop 0", L1(k_snop), 64);
+    run("fma + s_add pair", L1(k_valu_salu), 64);
     return 0;
 }
