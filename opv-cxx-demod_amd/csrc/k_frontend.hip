@@ -77,12 +77,12 @@ constexpr uint32_t kAhead = 56;                 // highest tap is floor(pos) + 5
 static_assert((kRing & (kRing - 1)) == 0, "ring must be a power of two");
 
 // LDS map (bytes): ring | guard | reduction scratch (12 doubles) | write sink for non-leader lanes |
-// atan table (32 rows x 12 doubles: c0..c9, interval centre, pad)
+// atan table (33 rows x 10 doubles: c0..c8, pad)
 constexpr uint32_t kRedOff = kRingBytes + kGuardBytes;   // 16400
 constexpr uint32_t kSinkOff = kRedOff + 96;              // 16496
 constexpr uint32_t kTabOff = kSinkOff + 64 * 8 + 80;     // 17088
-constexpr uint32_t kTabRow = 12;
-constexpr uint32_t kLdsBytes = kTabOff + 32 * kTabRow * 8;  // 20160 <= 20480: eight workgroups per CU
+constexpr uint32_t kTabRow = 10;
+constexpr uint32_t kLdsBytes = kTabOff + 33 * kTabRow * 8;  // 19728 <= 20480: eight workgroups per CU
 static_assert(kTabOff % 16 == 0 && kRedOff % 16 == 0, "16-byte LDS alignment");
 
 typedef __attribute__((address_space(1))) double gdouble;
@@ -167,11 +167,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
     const unsigned char* ringb = lds;
     const double* red = reinterpret_cast<const double*>(lds + kRedOff);
     double* atab = reinterpret_cast<double*>(lds + kTabOff);
-    for (int i = lane; i < 32 * (int)kTabRow; i += 64) {
-        const int k = i / (int)kTabRow, c = i - k * (int)kTabRow;
-        // interval 0 is expanded at 0 (odd series), the others at their centre (k + 0.5)/32
-        atab[i] = c < 10 ? kOpvAtanTab[k][c] : (c == 10 && k ? ((double)k + 0.5) * (1.0 / 32.0) : 0.0);
-    }
+    for (int i = lane; i < 33 * (int)kTabRow; i += 64) atab[i] = (&kOpvAtanTab[0][0])[i];
 
     // ---- per-lane constants -------------------------------------------------------------
     const double kf = (double)(lane - 10);
@@ -189,13 +185,20 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
     sck.s3 = 0x1.71de256e9bdffp-19; sck.s4 = -0x1.add325df5e3b5p-26;
     sck.c0 = -0x1.0000000000000p-1; sck.c1 = 0x1.5555555555014p-5; sck.c2 = -0x1.6c16c16818f3fp-10;
     sck.c3 = 0x1.a019dfaa26924p-16; sck.c4 = -0x1.276f06eab6283p-22;
+    // Loop constants parked in VGPRs: one wave per SIMD has registers to spare, while hipcc
+    // otherwise keeps re-forming 64-bit literals in SGPR pairs inside the loop.
+    double kc_tfmax = 0.1, kc_beta = 0.00001, kc_alpha = 0.005, kc_fomax = 2000.0, kc_eps = 1e-10;
+    double kc_halfpi = 1.57079632679489661923, kc_32 = 32.0, kc_m1_32 = -1.0 / 32.0, kc_gain = st.afc_alpha * (kSymRate / kTwoPi);
+    asm volatile("" : "+v"(kc_tfmax), "+v"(kc_beta), "+v"(kc_alpha), "+v"(kc_fomax), "+v"(kc_eps));
+    asm volatile("" : "+v"(kc_halfpi), "+v"(kc_32), "+v"(kc_m1_32), "+v"(kc_gain));
+    double sx = 1.0, nsg = 1.0;          // +/-1.0 rebuilt per symbol by rewriting the high word only
+    asm volatile("" : "+v"(sx), "+v"(nsg));
     // where this lane parks its three row sums: row leaders in the scratch, the rest in a sink
     double* const red_wr = reinterpret_cast<double*>(lds + ((lane & 15) == 0 ? kRedOff + (uint32_t)(lane >> 4) * 8u
                                                                               : kSinkOff + (uint32_t)lane * 8u));
 
     // ---- carry ---------------------------------------------------------------------------
     double fo = st.freq_offset, tf = st.timing_freq, mu = st.mu;
-    const double afc_gain = st.afc_alpha * (kSymRate / kTwoPi);  // ref :300-302
     PrevSums qp{st.p1r, st.p1i, st.p2r, st.p2i, st.x40c, st.x40s}, qq{0, 0, 0, 0, 1, 0};    // previous on-time P1..P4 (S_1 = (a+b, c-d), S_2 = (a-b, c+d))
     double fo_sum = st.fo_sum;
     uint32_t origin = uni((uint32_t)st.origin);
@@ -226,7 +229,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "v"(gsrc), "s"(lds_byte)
+                     : "v"(gsrc), "s"(uni(lds_byte))
                      : "memory");
     };
     const uint32_t lds_base = uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds);
@@ -283,6 +286,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
         double pos = mu;                                   // ref :217
         const uint32_t soft_off0 = ((uint32_t)n_soft * 8u) & soft_bmask;  // ring byte offset of this call's first symbol
         uint32_t soft_off = soft_off0;
+        asm volatile("" : "+v"(soft_off));            // lives in a VGPR: it is the store's address operand
 
         // Tile bookkeeping for the symbol at `at` (wave-uniform, rare). Returns how many FOLLOWING
         // symbols need neither it nor the end-of-call test: pos advances by at most 42 samples per
@@ -315,15 +319,22 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
         // pos + kf. Issued for symbol k+1 as soon as pos(k+1) exists.
         int w0 = 0, w1 = 0;
         double f = 0.0;
-        auto fetch = [&](double at, bool clamp0) {
+        uint32_t tap_byte = 0;
+        auto fetch_addr = [&](double at, bool clamp0) {
             double p = at + kf;
             if (clamp0) p = fmax(p, 0.0);                  // early gate before the chunk: s[0] (ref :237)
             const int idx = (int)p;
             f = __builtin_amdgcn_fract(p);                 // p - idx, p >= 0
-            const uint32_t byte = (((uint32_t)idx + origin) << 2) & (kRingBytes - 4u);
-            const int* tap = reinterpret_cast<const int*>(ringb + byte);
+            tap_byte = (((uint32_t)idx + origin) << 2) & (kRingBytes - 4u);
+        };
+        auto fetch_read = [&]() {
+            const int* tap = reinterpret_cast<const int*>(ringb + tap_byte);
             w0 = tap[0];
             w1 = tap[1];
+        };
+        auto fetch = [&](double at, bool clamp0) {
+            fetch_addr(at, clamp0);
+            fetch_read();
         };
 
         // One symbol: correlate the fetched taps, run both loop filters, log the soft value, fetch
@@ -385,18 +396,20 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             const double en1 = fma(s1r_, s1r_, s1i_ * s1i_);        // ref :264-265
             const double en2 = fma(s2r_, s2r_, s2i_ * s2i_);
             const double soft = en2 - en1;                          // ref :268
-            const bool dom1 = en2 < en1;                            // e1 > e2 (ref :272 / :291)
-            // dominant tone of every gate: C = (P1 + sg P2, P3 - sg P4), sg = +1 tone 1, -1 tone 2
-            const double sg = dom1 ? 1.0 : -1.0;
+            // dominant tone: 1 iff e1 > e2 (ref :272 / :291), i.e. soft < 0 (a tie gives +0: tone 2).
+            // Every gate's dominant correlation is C = (P1 + sg P2, P3 - sg P4), sg = +1 for tone 1,
+            // -1 for tone 2 = -copysign(1, soft): one bit-field insert, no compare.
+            nsg = mkd((dhi(soft) & (int)0x80000000) | 0x3ff00000, dlo(nsg));
+            const double sg = -nsg;
             double ted, pd = 0.0;
             [[maybe_unused]] double dr = 0, di = 0, cx = 0, cy = 0, ax = 0, ay = 0, mx = 1.0, ratio = 0;
-            [[maybe_unused]] double2 c01{0, 0}, c23{0, 0}, c45{0, 0}, c67{0, 0}, c89{0, 0};
-            [[maybe_unused]] double centre = 0;
+            [[maybe_unused]] double2 c01{0, 0}, c23{0, 0}, c45{0, 0}, c67{0, 0};
+            [[maybe_unused]] double c8 = 0, h = 0;
             if constexpr (kFirst) {
                 const double er = fma(sg, P2e, P1e), ei = fma(-sg, P4e, P3e);
                 const double lr2 = fma(sg, P2l, P1l), li2 = fma(-sg, P4l, P3l);
                 const double ee = fma(er, er, ei * ei), el = fma(lr2, lr2, li2 * li2);
-                const double num = el - ee, den = el + ee + 1e-10;  // ted = num/den (ref :275/:279)
+                const double num = el - ee, den = el + ee + kc_eps;  // ted = num/den (ref :275/:279)
                 double y = __builtin_amdgcn_rcp(den);
                 y = fma(fma(-den, y, 1.0), y, y);
                 y = fma(fma(-den, y, 1.0), y, y);
@@ -419,7 +432,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 const double er = fma(sg, P2e, P1e), ei = fma(-sg, P4e, P3e);
                 const double lr2 = fma(sg, P2l, P1l), li2 = fma(-sg, P4l, P3l);
                 const double ee = fma(er, er, ei * ei), el = fma(lr2, lr2, li2 * li2);
-                const double num = el - ee, den = el + ee + 1e-10;  // ted = num/den (ref :275/:279)
+                const double num = el - ee, den = el + ee + kc_eps;  // ted = num/den (ref :275/:279)
 
                 // the two divides of the symbol on one reciprocal: ted and mn/mx for the phase
                 // detector; den in [1e-10, 2e12], dm in [1e-100, 1e12]
@@ -433,34 +446,38 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 ratio = fma(fma(-dm, ratio, mn), idm, ratio);
                 // atan2(cy, cx): table row by interval of ratio (the row's LDS latency is covered by
                 // the timing loop below)
-                int k = (int)(ratio * 32.0);
-                k = k > 31 ? 31 : k;
+                const double kd = rint(ratio * kc_32);              // nearest expansion point k/32, k = 0..32
+                const int k = (int)kd;
+                h = fma(kd, kc_m1_32, ratio);                       // |h| <= 1/64
                 const double2* trow = reinterpret_cast<const double2*>(atab + k * (int)kTabRow);
-                c89 = trow[4]; c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
-                centre = atab[k * (int)kTabRow + 10];
+                c8 = atab[k * (int)kTabRow + 8]; c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
                 ted = num * iden;
                 ted = fma(fma(-den, ted, num), iden, ted);
             }
             __builtin_amdgcn_sched_barrier(0);
 
             // ---- timing loop, soft log, next symbol's taps ------------------------------------------
-            tf = clampd(fma(0.00001, ted, tf), -0.1, 0.1);          // beta (ref :118,:283-284)
-            const double adj = clampd(fma(0.005, ted, tf), -2.0, 2.0);  // alpha (ref :117,:285-286)
+            tf = clampd(fma(kc_beta, ted, tf), -kc_tfmax, kc_tfmax);  // beta (ref :118,:283-284)
+            const double adj = clampd(fma(kc_alpha, ted, tf), -2.0, 2.0);  // alpha (ref :117,:285-286)
             pos += 40.0 + adj;                                      // ref :313
-            [[maybe_unused]] double h = 0;
-            if constexpr (!kFirst) {
-                h = ratio - centre;                                 // first use of the table row: its wait sits
-                asm volatile("" : "+v"(h));                         //   here, before the taps are requested
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            fetch(pos, false);                                      // pos >= 38 after any symbol
+            fetch_addr(pos, false);                                 // pos >= 38 after any symbol
             *(gdouble*)(soft_base + my_soft_off) = soft;            // all lanes, same value and address
+            fo_sum += fo;                                           // sum of the fo every symbol USED
+            [[maybe_unused]] double pd_off = 0;
+            if constexpr (!kFirst) {
+                // cx < 0: pi - pd, as a +/-1 multiplier and a 0/pi offset built from the sign bit
+                sx = mkd((dhi(cx) & (int)0x80000000) | 0x3ff00000, dlo(sx));
+                pd_off = fma(-sx, kc_halfpi, kc_halfpi);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): table row landed; waited for here,
+                __builtin_amdgcn_sched_barrier(0);                  //   before the taps are requested
+            }
+            fetch_read();
             __builtin_amdgcn_sched_barrier(0);
 
             // ---- AFC ------------------------------------------------------------------------------
             if constexpr (!kFirst) {
-                pd = fma(c89.y, h, c89.x);                          // degree-9 Horner
-                pd = fma(pd, h, c67.y);
+                pd = fma(c8, h, c67.y);                             // degree-8 Horner
                 pd = fma(pd, h, c67.x);
                 pd = fma(pd, h, c45.y);
                 pd = fma(pd, h, c45.x);
@@ -468,9 +485,9 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 pd = fma(pd, h, c23.x);
                 pd = fma(pd, h, c01.y);
                 pd = fma(pd, h, c01.x);
-                pd = (ay > ax) ? 1.57079632679489661923 - pd : pd;  // octant fix-up
-                pd = (cx < 0.0) ? 3.14159265358979323846 - pd : pd;
-                pd = (cy < 0.0) ? -pd : pd;
+                pd = (ay > ax) ? kc_halfpi - pd : pd;               // octant fix-up
+                pd = fma(sx, pd, pd_off);
+                pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));  // sign of cy
 
                 if (__builtin_expect(uni_eq(mx, 0.0), 0)) {
                     // Digital silence on either side. The reference's product (ref :299) is then
@@ -484,6 +501,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                     // prev_t = P_t conj(E_t(k)), P_t = S_t(k-1) (-/+ j) X40(k-1),
                     // E_t(k) = exp(j(-/+ k pi/2 + (80 pi/Fs) sum_{j<k} fo_j)).
                     // Rare and wave-uniform; rebuilt here from the running sum of fo.
+                    const bool dom1 = soft < 0.0;
                     const double pr = dom1 ? prv.a + prv.b : prv.a - prv.b, pi = dom1 ? prv.c - prv.d : prv.c + prv.d;
                     const bool dom_zero = (dr == 0.0 && di == 0.0), prev_zero = (pr == 0.0 && pi == 0.0);
                     pd = 0.0;
@@ -512,8 +530,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                     }
                 }
             }
-            fo_sum += fo;                                           // sum of the fo every symbol USED
-            if constexpr (!kFirst) fo = clampd(fma(afc_gain, pd, fo), -2000.0, 2000.0);  // ref :300-303
+            if constexpr (!kFirst) fo = clampd(fma(kc_gain, pd, fo), -kc_fomax, kc_fomax);  // ref :300-303
             // prev <- this symbol's on-time correlations (ref :309-310)
             cur.a = P1o; cur.b = P2o; cur.c = P3o; cur.d = P4o;
         };
