@@ -361,28 +361,51 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             const double v3 = zi * bE, v4 = zi * bO, v5 = zi * bL;    // P2 = sum Zi b
             const double v6 = zi * aE, v7 = zi * aO, v8 = zi * aL;    // P3 = sum Zi a
             const double v9 = zr * bE, v10 = zr * bO, v11 = zr * bL;  // P4 = sum Zr b
-            const double r0 = swap32_add(v0, v6), r1 = swap32_add(v1, v7), r2 = swap32_add(v2, v8);
-            const double r3 = swap32_add(v3, v9), r4 = swap32_add(v4, v10), r5 = swap32_add(v5, v11);
-            double q0 = swap16_add(r0, r3), q1 = swap16_add(r1, r4), q2 = swap16_add(r2, r5);
-            // row all-sums, the three chains interleaved step by step: a DPP read needs two issue
-            // slots behind the VALU write of its source, the other two chains fill them
+            // The ON-TIME sums first: their LDS round trip then runs under the early/late reduction,
+            // and the early/late one under the on-time arithmetic of the tail. The lone DPP chain of
+            // the on-time value is interleaved with early/late swaps (a DPP read needs two issue
+            // slots behind the VALU write of its source).
+            const double r1 = swap32_add(v1, v7), r4 = swap32_add(v4, v10);
+            double q1 = swap16_add(r1, r4);                          // rows 0..3: P1o..P4o partials
             __builtin_amdgcn_sched_barrier(0);
-            q0 = dpp_add<0x128>(q0); q1 = dpp_add<0x128>(q1); q2 = dpp_add<0x128>(q2);
+            q1 = dpp_add<0x128>(q1);
             __builtin_amdgcn_sched_barrier(0);
-            q0 = dpp_add<0x124>(q0); q1 = dpp_add<0x124>(q1); q2 = dpp_add<0x124>(q2);
+            const double r0 = swap32_add(v0, v6);
             __builtin_amdgcn_sched_barrier(0);
-            q0 = dpp_add<0x122>(q0); q1 = dpp_add<0x122>(q1); q2 = dpp_add<0x122>(q2);
+            q1 = dpp_add<0x124>(q1);
             __builtin_amdgcn_sched_barrier(0);
-            q0 = dpp_add<0x121>(q0); q1 = dpp_add<0x121>(q1); q2 = dpp_add<0x121>(q2);
+            const double r2 = swap32_add(v2, v8);
             __builtin_amdgcn_sched_barrier(0);
-            // row r holds P_{r+1}{E,O,L}; scratch layout [O: P1..P4 | E: P1..P4 | L: P1..P4], the
-            // on-time sums first because the tail needs them first
-            red_wr[0] = q1; red_wr[4] = q0; red_wr[8] = q2;
+            q1 = dpp_add<0x122>(q1);
+            __builtin_amdgcn_sched_barrier(0);
+            const double r3 = swap32_add(v3, v9);
+            __builtin_amdgcn_sched_barrier(0);
+            q1 = dpp_add<0x121>(q1);
+            __builtin_amdgcn_sched_barrier(0);
+            const double r5 = swap32_add(v5, v11);
+            // scratch layout [O: P1..P4 | E: P1..P4 | L: P1..P4]; row r holds P_{r+1}
+            red_wr[0] = q1;
             __builtin_amdgcn_wave_barrier();
-            const double P1o = red[0], P2o = red[1], P3o = red[2], P4o = red[3];
+            double P1o = red[0], P2o = red[1], P3o = red[2], P4o = red[3];
+            __builtin_amdgcn_sched_barrier(0);
+            double q0 = swap16_add(r0, r3), q2 = swap16_add(r2, r5);
+            __builtin_amdgcn_sched_barrier(0);
+            q0 = dpp_add<0x128>(q0); q2 = dpp_add<0x128>(q2);
+            __builtin_amdgcn_sched_barrier(0);
+            q0 = dpp_add<0x124>(q0); q2 = dpp_add<0x124>(q2);
+            __builtin_amdgcn_sched_barrier(0);
+            q0 = dpp_add<0x122>(q0); q2 = dpp_add<0x122>(q2);
+            __builtin_amdgcn_sched_barrier(0);
+            q0 = dpp_add<0x121>(q0); q2 = dpp_add<0x121>(q2);
+            __builtin_amdgcn_sched_barrier(0);
+            // the on-time sums have long landed: take their wait here, before more LDS traffic is queued
+            asm volatile("" : "+v"(P1o), "+v"(P2o), "+v"(P3o), "+v"(P4o));
+            __builtin_amdgcn_sched_barrier(0);
+            red_wr[4] = q0; red_wr[8] = q2;
+            __builtin_amdgcn_wave_barrier();
             const double P1e = red[4], P2e = red[5], P3e = red[6], P4e = red[7];
             const double P1l = red[8], P2l = red[9], P3l = red[10], P4l = red[11];
-            // in the shadow of that round trip: this symbol's X[40] for the next one (lane 50)
+            // this symbol's X[40] for the next one (lane 50)
             cur.x40c = readlane_d(xc, 50);
             cur.x40s = readlane_d(xs, 50);
             const uint32_t my_soft_off = soft_off;
@@ -429,6 +452,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 ax = fabs(cx); ay = fabs(cy);
                 mx = fmax(ax, ay);
                 const double mn = fmin(ax, ay);
+                __builtin_amdgcn_sched_barrier(0);                  // early/late sums: first use, their wait sits here
                 const double er = fma(sg, P2e, P1e), ei = fma(-sg, P4e, P3e);
                 const double lr2 = fma(sg, P2l, P1l), li2 = fma(-sg, P4l, P3l);
                 const double ee = fma(er, er, ei * ei), el = fma(lr2, lr2, li2 * li2);
