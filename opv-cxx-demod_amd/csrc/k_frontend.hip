@@ -76,14 +76,11 @@ constexpr uint32_t kBack = 11;                  // lowest tap is floor(pos) - 10
 constexpr uint32_t kAhead = 56;                 // highest tap is floor(pos) + 54, one spare
 static_assert((kRing & (kRing - 1)) == 0, "ring must be a power of two");
 
-// LDS map (bytes): ring | guard | reduction scratch (12 doubles) | write sink for non-leader lanes |
-// atan table (33 rows x 10 doubles: c0..c8, pad)
-constexpr uint32_t kRedOff = kRingBytes + kGuardBytes;   // 16400
-constexpr uint32_t kSinkOff = kRedOff + 96;              // 16496
-constexpr uint32_t kTabOff = kSinkOff + 64 * 8 + 80;     // 17088
+// LDS map (bytes): ring | guard | atan table (33 rows x 10 doubles: c0..c8, pad)
+constexpr uint32_t kTabOff = kRingBytes + kGuardBytes;   // 16400
 constexpr uint32_t kTabRow = 10;
-constexpr uint32_t kLdsBytes = kTabOff + 33 * kTabRow * 8;  // 19728 <= 20480: eight workgroups per CU
-static_assert(kTabOff % 16 == 0 && kRedOff % 16 == 0, "16-byte LDS alignment");
+constexpr uint32_t kLdsBytes = kTabOff + 33 * kTabRow * 8;  // 19040 <= 20480: eight workgroups per CU
+static_assert(kTabOff % 16 == 0, "16-byte LDS alignment");
 
 typedef __attribute__((address_space(1))) double gdouble;
 typedef __attribute__((address_space(1))) unsigned char gbyte;
@@ -165,7 +162,6 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
     const unsigned char* ringb = lds;
-    const double* red = reinterpret_cast<const double*>(lds + kRedOff);
     double* atab = reinterpret_cast<double*>(lds + kTabOff);
     for (int i = lane; i < 33 * (int)kTabRow; i += 64) atab[i] = (&kOpvAtanTab[0][0])[i];
 
@@ -193,9 +189,6 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
     asm volatile("" : "+v"(kc_halfpi), "+v"(kc_32), "+v"(kc_m1_32), "+v"(kc_gain));
     double sx = 1.0, nsg = 1.0;          // +/-1.0 rebuilt per symbol by rewriting the high word only
     asm volatile("" : "+v"(sx), "+v"(nsg));
-    // where this lane parks its three row sums: row leaders in the scratch, the rest in a sink
-    double* const red_wr = reinterpret_cast<double*>(lds + ((lane & 15) == 0 ? kRedOff + (uint32_t)(lane >> 4) * 8u
-                                                                              : kSinkOff + (uint32_t)lane * 8u));
 
     // ---- carry ---------------------------------------------------------------------------
     double fo = st.freq_offset, tf = st.timing_freq, mu = st.mu;
@@ -341,12 +334,16 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
         // the next symbol's taps. kFirst: first symbol of a demodulate() call, no AFC update
         // (ref :289). `cur` receives this symbol's on-time sums and X[40], `prv` holds the
         // previous symbol's.
-        // The sched_barriers pin the order in which the wave issues the three LDS round trips so
-        // that each is covered by arithmetic that does not depend on it: scratch reads <- X[40]
-        // hand-over; atan table row <- the whole timing loop; next taps <- the atan polynomial.
+        // Order of events (pinned with sched_barriers; a lone wave only issues, it never overlaps):
+        //   1. on-time products -> reduce (4 values) -> v_readlane to every lane: soft, dominant tone
+        //   2. early/late products OF THE DOMINANT TONE ONLY (the tone is known by now: 4 values to
+        //      reduce instead of 8) -> reduce, the single DPP chain padded with the AFC operand
+        //      arithmetic -> 32 B through LDS, the round trip under the rest of that arithmetic
+        //   3. one reciprocal for both divides -> atan table row requested -> timing loop, soft
+        //      store, tap address under that LDS latency -> taps requested -> atan polynomial
         auto symbol = [&](auto first_tag, PrevSums& cur, const PrevSums& prv) {
             constexpr bool kFirst = decltype(first_tag)::value;
-            // ---- the lane's sample, LO factor and 12 partial products ----------------------------
+            // ---- the lane's sample and LO factor ----------------------------------------------------
             const int s0r = (int)(short)(w0 & 0xFFFF), s0i = w0 >> 16;      // ref :1023
             const int d_r = (int)(short)(w1 & 0xFFFF) - s0r, d_i = (w1 >> 16) - s0i;
             const double lr = fma(f, (double)d_r, (double)s0r);              // ref :122-128
@@ -356,108 +353,134 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             // Z = Lam * conj(X)
             const double zr = fma(lr, xc, li * xs);
             const double zi = fma(li, xc, -(lr * xs));
-            // value order v[3r+k]: row r = P-term (P1..P4), k = gate (E,O,L)
-            const double v0 = zr * aE, v1 = zr * aO, v2 = zr * aL;    // P1 = sum Zr a
-            const double v3 = zi * bE, v4 = zi * bO, v5 = zi * bL;    // P2 = sum Zi b
-            const double v6 = zi * aE, v7 = zi * aO, v8 = zi * aL;    // P3 = sum Zi a
-            const double v9 = zr * bE, v10 = zr * bO, v11 = zr * bL;  // P4 = sum Zr b
-            // The ON-TIME sums first: their LDS round trip then runs under the early/late reduction,
-            // and the early/late one under the on-time arithmetic of the tail. The lone DPP chain of
-            // the on-time value is interleaved with early/late swaps (a DPP read needs two issue
-            // slots behind the VALU write of its source).
-            const double r1 = swap32_add(v1, v7), r4 = swap32_add(v4, v10);
-            double q1 = swap16_add(r1, r4);                          // rows 0..3: P1o..P4o partials
+
+            // ---- 1. on-time gate: P1 = sum Zr a, P2 = sum Zi b, P3 = sum Zi a, P4 = sum Zr b ------
+            // Reduce-scatter over the wave (permlane32 / permlane16 swaps), row all-sum by DPP
+            // rotations, v_readlane to every lane. Swaps and DPP reads need one or two issue slots
+            // behind the VALU write of their source: the sigma-free halves of the early/late
+            // products, the X[40] hand-over (lane 50) and the soft-ring cursor fill them.
+            const double o1 = zr * aO, o2 = zi * bO, o3 = zi * aO, o4 = zr * bO;
+            const double eA = zr * aE;
+            __builtin_amdgcn_sched_barrier(0);
+            const double r13 = swap32_add(o1, o3), r24 = swap32_add(o2, o4);
+            __builtin_amdgcn_sched_barrier(0);
+            const double eB = zi * aE, lA = zr * aL;
+            __builtin_amdgcn_sched_barrier(0);
+            double q1 = swap16_add(r13, r24);                       // rows 0..3: P1o..P4o partials
+            __builtin_amdgcn_sched_barrier(0);
+            double lB = zi * aL;
+            asm volatile("" : "+v"(lB));
+            cur.x40c = readlane_d(xc, 50);
             __builtin_amdgcn_sched_barrier(0);
             q1 = dpp_add<0x128>(q1);
             __builtin_amdgcn_sched_barrier(0);
-            const double r0 = swap32_add(v0, v6);
+            cur.x40s = readlane_d(xs, 50);
             __builtin_amdgcn_sched_barrier(0);
             q1 = dpp_add<0x124>(q1);
             __builtin_amdgcn_sched_barrier(0);
-            const double r2 = swap32_add(v2, v8);
+            const uint32_t my_soft_off = soft_off;
+            soft_off = (soft_off + 8u) & soft_bmask;
+            asm volatile("" : "+v"(soft_off));                      // (empty asm: keeps the filler in its slot)
             __builtin_amdgcn_sched_barrier(0);
             q1 = dpp_add<0x122>(q1);
             __builtin_amdgcn_sched_barrier(0);
-            const double r3 = swap32_add(v3, v9);
+            const double fo_sum_next = fo_sum + fo;                 // sum of the fo every symbol USED
+            asm volatile("" : "+v"(fo_sum), "+v"(fo));
             __builtin_amdgcn_sched_barrier(0);
             q1 = dpp_add<0x121>(q1);
             __builtin_amdgcn_sched_barrier(0);
-            const double r5 = swap32_add(v5, v11);
-            // scratch layout [O: P1..P4 | E: P1..P4 | L: P1..P4]; row r holds P_{r+1}
-            red_wr[0] = q1;
-            __builtin_amdgcn_wave_barrier();
-            double P1o = red[0], P2o = red[1], P3o = red[2], P4o = red[3];
+            const double P1o = readlane_d(q1, 0), P3o = readlane_d(q1, 32);
+            double P2o = readlane_d(q1, 16), P4o = readlane_d(q1, 48);
+            asm volatile("" : "+v"(P2o), "+v"(P4o));                // one scalar source per instruction: these two in VGPRs
             __builtin_amdgcn_sched_barrier(0);
-            double q0 = swap16_add(r0, r3), q2 = swap16_add(r2, r5);
-            __builtin_amdgcn_sched_barrier(0);
-            q0 = dpp_add<0x128>(q0); q2 = dpp_add<0x128>(q2);
-            __builtin_amdgcn_sched_barrier(0);
-            q0 = dpp_add<0x124>(q0); q2 = dpp_add<0x124>(q2);
-            __builtin_amdgcn_sched_barrier(0);
-            q0 = dpp_add<0x122>(q0); q2 = dpp_add<0x122>(q2);
-            __builtin_amdgcn_sched_barrier(0);
-            q0 = dpp_add<0x121>(q0); q2 = dpp_add<0x121>(q2);
-            __builtin_amdgcn_sched_barrier(0);
-            // the on-time sums have long landed: take their wait here, before more LDS traffic is queued
-            asm volatile("" : "+v"(P1o), "+v"(P2o), "+v"(P3o), "+v"(P4o));
-            __builtin_amdgcn_sched_barrier(0);
-            red_wr[4] = q0; red_wr[8] = q2;
-            __builtin_amdgcn_wave_barrier();
-            const double P1e = red[4], P2e = red[5], P3e = red[6], P4e = red[7];
-            const double P1l = red[8], P2l = red[9], P3l = red[10], P4l = red[11];
-            // this symbol's X[40] for the next one (lane 50)
-            cur.x40c = readlane_d(xc, 50);
-            cur.x40s = readlane_d(xs, 50);
-            const uint32_t my_soft_off = soft_off;
-            soft_off = (soft_off + 8u) & soft_bmask;
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_wave_barrier();
 
-            // ---- uniform tail (all lanes, identical) -------------------------------------------
             const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;        // S_1 (tone -13550)
             const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;        // S_2 (tone +13550)
             const double en1 = fma(s1r_, s1r_, s1i_ * s1i_);        // ref :264-265
             const double en2 = fma(s2r_, s2r_, s2i_ * s2i_);
             const double soft = en2 - en1;                          // ref :268
             // dominant tone: 1 iff e1 > e2 (ref :272 / :291), i.e. soft < 0 (a tie gives +0: tone 2).
-            // Every gate's dominant correlation is C = (P1 + sg P2, P3 - sg P4), sg = +1 for tone 1,
+            // A gate's dominant correlation is C = (P1 + sg P2, P3 - sg P4), sg = +1 for tone 1,
             // -1 for tone 2 = -copysign(1, soft): one bit-field insert, no compare.
             nsg = mkd((dhi(soft) & (int)0x80000000) | 0x3ff00000, dlo(nsg));
             const double sg = -nsg;
+
+            // ---- 2. early / late gates, dominant tone only: C = sum (Zr a + sg Zi b, Zi a - sg Zr b)
+            // Same reduction on 4 values; its slots are filled with the phase detector operands:
+            // dom * conj(prev) (ref :299). prev of the reference = S_prev advanced by one symbol of LO
+            // rotation, (-/+ j) X40_prev; applied to the product:
+            //   z = (S conj(S_prev)) * conj(X40_prev) * (+/- j)
+            // With the previous S scaled by sg (prs = sg pr, pis = sg pi) the (+/- j) becomes a fixed
+            // one: z = (cx, cy).
+            const double szi = sg * zi, szr = sg * zr;
+            const double wEr = fma(szi, bE, eA), wEi = fma(-szr, bE, eB);
+            const double wLr = fma(szi, bL, lA), wLi = fma(-szr, bL, lB);
             double ted, pd = 0.0;
-            [[maybe_unused]] double dr = 0, di = 0, cx = 0, cy = 0, ax = 0, ay = 0, mx = 1.0, ratio = 0;
+            [[maybe_unused]] double dr = 0, di = 0, cx = 0, cy = 0, ax = 0, ay = 0, mx = 1.0, mn = 0, ratio = 0;
             [[maybe_unused]] double2 c01{0, 0}, c23{0, 0}, c45{0, 0}, c67{0, 0};
             [[maybe_unused]] double c8 = 0, h = 0;
+            double q2;
             if constexpr (kFirst) {
-                const double er = fma(sg, P2e, P1e), ei = fma(-sg, P4e, P3e);
-                const double lr2 = fma(sg, P2l, P1l), li2 = fma(-sg, P4l, P3l);
-                const double ee = fma(er, er, ei * ei), el = fma(lr2, lr2, li2 * li2);
-                const double num = el - ee, den = el + ee + kc_eps;  // ted = num/den (ref :275/:279)
+                const double hre = swap32_add(wEr, wLr), him = swap32_add(wEi, wLi);   // lanes <32: E, >=32: L
+                q2 = swap16_add(hre, him);                          // rows: E.re, E.im, L.re, L.im partials
+                q2 = dpp_add<0x128>(q2);
+                q2 = dpp_add<0x124>(q2);
+                q2 = dpp_add<0x122>(q2);
+                q2 = dpp_add<0x121>(q2);
+            } else {
+                dr = fma(sg, P2o, P1o);
+                asm volatile("" : "+v"(dr));
+                __builtin_amdgcn_sched_barrier(0);
+                const double hre = swap32_add(wEr, wLr), him = swap32_add(wEi, wLi);   // lanes <32: E, >=32: L
+                __builtin_amdgcn_sched_barrier(0);
+                di = fma(-sg, P4o, P3o);
+                double prs = fma(sg, prv.a, prv.b);
+                asm volatile("" : "+v"(di), "+v"(prs));
+                __builtin_amdgcn_sched_barrier(0);
+                q2 = swap16_add(hre, him);                          // rows: E.re, E.im, L.re, L.im partials
+                __builtin_amdgcn_sched_barrier(0);
+                double pis = fma(sg, prv.c, -prv.d);
+                double t_ar = di * pis;
+                asm volatile("" : "+v"(pis), "+v"(t_ar));
+                __builtin_amdgcn_sched_barrier(0);
+                q2 = dpp_add<0x128>(q2);
+                __builtin_amdgcn_sched_barrier(0);
+                double ar = fma(dr, prs, t_ar);
+                double t_ai = dr * pis;
+                asm volatile("" : "+v"(ar), "+v"(t_ai));
+                __builtin_amdgcn_sched_barrier(0);
+                q2 = dpp_add<0x124>(q2);
+                __builtin_amdgcn_sched_barrier(0);
+                double ai = fma(di, prs, -t_ai);
+                double t_cy = ai * prv.x40s;
+                asm volatile("" : "+v"(ai), "+v"(t_cy));
+                __builtin_amdgcn_sched_barrier(0);
+                q2 = dpp_add<0x122>(q2);
+                __builtin_amdgcn_sched_barrier(0);
+                cy = fma(ar, prv.x40c, t_cy);                       // Im z
+                double t_cx = ai * prv.x40c;
+                asm volatile("" : "+v"(cy), "+v"(t_cx));
+                __builtin_amdgcn_sched_barrier(0);
+                q2 = dpp_add<0x121>(q2);
+                __builtin_amdgcn_sched_barrier(0);
+                cx = fma(ar, prv.x40s, -t_cx);                      // Re z
+                ax = fabs(cx); ay = fabs(cy);
+                mx = fmax(ax, ay);
+                mn = fmin(ax, ay);
+            }
+            const double Ere = readlane_d(q2, 0), Eim = readlane_d(q2, 16), Lre = readlane_d(q2, 32), Lim = readlane_d(q2, 48);
+            __builtin_amdgcn_sched_barrier(0);
+            const double ee = fma(Ere, Ere, Eim * Eim), el = fma(Lre, Lre, Lim * Lim);
+            const double num = el - ee, den = el + ee + kc_eps;     // ted = num/den (ref :275/:279)
+
+            // ---- 3. divides, timing loop, AFC ---------------------------------------------------------
+            if constexpr (kFirst) {
                 double y = __builtin_amdgcn_rcp(den);
                 y = fma(fma(-den, y, 1.0), y, y);
                 y = fma(fma(-den, y, 1.0), y, y);
                 ted = num * y;
                 ted = fma(fma(-den, ted, num), y, ted);
             } else {
-                // phase detector operands: dom * conj(prev) (ref :299). prev of the reference = S_prev
-                // advanced by one symbol of LO rotation, (-/+ j) X40_prev; applied to the product:
-                //   z = (S conj(S_prev)) * conj(X40_prev) * (+/- j)
-                // With the previous S scaled by sg (prs = sg pr, pis = sg pi) the (+/- j) becomes a
-                // fixed one: z = (cx, cy) below.
-                dr = fma(sg, P2o, P1o); di = fma(-sg, P4o, P3o);
-                const double prs = fma(sg, prv.a, prv.b), pis = fma(sg, prv.c, -prv.d);
-                const double ar = fma(dr, prs, di * pis), ai = fma(di, prs, -(dr * pis));
-                cy = fma(ar, prv.x40c, ai * prv.x40s);              // Im z
-                cx = fma(ar, prv.x40s, -(ai * prv.x40c));           // Re z
-                ax = fabs(cx); ay = fabs(cy);
-                mx = fmax(ax, ay);
-                const double mn = fmin(ax, ay);
-                __builtin_amdgcn_sched_barrier(0);                  // early/late sums: first use, their wait sits here
-                const double er = fma(sg, P2e, P1e), ei = fma(-sg, P4e, P3e);
-                const double lr2 = fma(sg, P2l, P1l), li2 = fma(-sg, P4l, P3l);
-                const double ee = fma(er, er, ei * ei), el = fma(lr2, lr2, li2 * li2);
-                const double num = el - ee, den = el + ee + kc_eps;  // ted = num/den (ref :275/:279)
-
                 // the two divides of the symbol on one reciprocal: ted and mn/mx for the phase
                 // detector; den in [1e-10, 2e12], dm in [1e-100, 1e12]
                 const double dm = fmax(mx, 1e-100);                 // digital silence: 0/1e-100 = 0, fixed up below
@@ -486,7 +509,6 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             pos += 40.0 + adj;                                      // ref :313
             fetch_addr(pos, false);                                 // pos >= 38 after any symbol
             *(gdouble*)(soft_base + my_soft_off) = soft;            // all lanes, same value and address
-            fo_sum += fo;                                           // sum of the fo every symbol USED
             [[maybe_unused]] double pd_off = 0;
             if constexpr (!kFirst) {
                 // cx < 0: pi - pd, as a +/-1 multiplier and a 0/pi offset built from the sign bit
@@ -555,6 +577,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 }
             }
             if constexpr (!kFirst) fo = clampd(fma(kc_gain, pd, fo), -kc_fomax, kc_fomax);  // ref :300-303
+            fo_sum = fo_sum_next;                                   // (the silence rule above needs the sum BEFORE this symbol)
             // prev <- this symbol's on-time correlations (ref :309-310)
             cur.a = P1o; cur.b = P2o; cur.c = P3o; cur.d = P4o;
         };

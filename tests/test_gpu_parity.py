@@ -565,3 +565,71 @@ def test_pathological_inputs_match_the_oracle(amd, oracle, iq10):
         exp = oracle.receive(caps[k], streaming=False)
         assert np.array_equal(g["frames"], exp["frames"]) and g["state"].total_symbols == exp["n_soft"], k
         d.close()
+
+
+def _gapped_capture(oracle, iq10):
+    """10 frames, 1.2 kHz off tune, ~300 gaps of exact zeros. Gap edges that would leave a symbol
+    window with ONE non-zero tap are nudged until the oracle sees none (see the test below)."""
+    base = impair(iq10, amp=6000.0, f0_hz=1200.0).reshape(-1, 2)
+    rng = np.random.default_rng(5)
+    pos, gaps = 3000, []
+    while pos + 400 < base.shape[0]:
+        glen = int(rng.integers(105, 260))          # >= one whole 60-sample correlation window of zeros
+        gaps.append([pos, glen])
+        pos += glen + int(rng.integers(1500, 4000))
+
+    def build():
+        z = base.copy()
+        for p, n in gaps:
+            z[p:p + n] = 0
+        return z.reshape(-1)
+
+    for _ in range(200):
+        x = build()
+        soft = oracle.receive(x, streaming=True)["soft"]
+        amb = np.nonzero((soft != 0) & (np.abs(soft) < 1.0))[0]            # energies are ~1e10
+        if amb.size == 0:
+            return x, [g[0] for g in gaps]
+        at = 40 * int(amb[0])                                                # roughly the sample position
+        j = int(np.argmin([min(abs(p - at), abs(p + n - at)) for p, n in gaps]))
+        if abs(gaps[j][0] - at) < abs(gaps[j][0] + gaps[j][1] - at):
+            gaps[j][0] -= 3; gaps[j][1] += 3                                 # leading edge 3 samples earlier
+        else:
+            gaps[j][1] += 3                                                  # trailing edge 3 samples later
+    raise AssertionError("could not remove the tie symbols")
+
+
+@pytest.mark.gpu
+def test_many_silence_gaps_signed_zero_rule(amd, oracle, iq10):
+    """Hundreds of digital-silence gaps inside a capture that sits 1.2 kHz off tune: every gap edge
+    makes the reference's phase detector take std::arg of an exact zero, whose value (0 or pi, a
+    27 Hz step of the AFC) depends on the signs of zeros and so on the ABSOLUTE LO phase the
+    reference carries (k_frontend's silence rule, rebuilt from the running sum of fo). One wrong
+    decision shows up in the per-chunk AFC state and in every soft symbol after it.
+
+    Not comparable, and kept out of the capture: a symbol whose window holds ONE non-zero tap next
+    to silence. Both tone energies are then |s|^2 exactly, and the reference's `e1 > e2` is decided
+    by the rounding of its own cos^2+sin^2 (the oracle shows soft = -/+2^-31 there); no
+    implementation that does not replay the reference's LO bit for bit can follow that coin toss.
+    In batch mode (another timing trajectory) the comparison stops at the first such symbol."""
+    x, starts = _gapped_capture(oracle, iq10)
+    assert len(starts) > 250
+    for streaming in (True, False):
+        exp = oracle.receive(x, streaming=streaming)
+        amb = np.nonzero((exp["soft"] != 0) & (np.abs(exp["soft"]) < 1.0))[0]
+        k_end = int(amb[0]) if amb.size else exp["n_soft"]
+        covered = sum(1 for p in starts if p < 38 * k_end)
+        assert covered > (250 if streaming else 20), (k_end, covered)
+        d = amd.Demod(1, max_samples=x.size // 2 + 64, streaming=streaming)
+        g = d.receive([x])[0]
+        d.close()
+        assert g["state"].total_symbols == exp["n_soft"]
+        assert g["chunks"].shape == exp["chunks"].shape
+        scale = np.mean(np.abs(exp["soft"])) + 1e-300
+        assert np.max(np.abs(g["soft"][:k_end] - exp["soft"][:k_end])) / scale < 1e-8
+        # freq_offset, timing_freq, mu, leftover, symbols of every demodulate() call that ended before k_end
+        done = np.nonzero(np.cumsum(exp["chunks"][:, 4]) <= k_end)[0]
+        if streaming:
+            assert done.size >= 10
+        for c in done:
+            assert np.allclose(g["chunks"][c], exp["chunks"][c], rtol=0, atol=1e-7), (c, g["chunks"][c], exp["chunks"][c])
