@@ -151,6 +151,43 @@ __device__ inline void expj_small(double kfs, double fo, const SinCosK& k, doubl
           [c0] "v"(k.c0), [c1] "v"(k.c1), [c2] "v"(k.c2), [c3] "v"(k.c3), [c4] "v"(k.c4));
 }
 
+// Digital silence on either side of the phase detector (rare, wave-uniform, kept out of line).
+// The reference's product dom * conj(prev) (ref :299) is then an exact zero whose SIGNS decide
+// std::arg: atan2(+0,-0) = pi, everything else +/-0 (IEEE). Working the signs through its
+// complex multiply:
+//   dom == (+0,+0), prev != 0 : pi iff Re(prev) < 0 and Im(prev) < 0
+//   prev == (+0,+0), dom != 0 : pi iff Re(dom)  < 0 and Im(dom)  < 0
+//   both zero                  : 0
+// where dom/prev are the reference's correlations, i.e. ours times the absolute LO phasor it
+// carries: c_t(k) = S_t(k) conj(E_t(k)), prev_t = P_t conj(E_t(k)), P_t = S_t(k-1) (-/+ j) X40(k-1),
+// E_t(k) = exp(j(-/+ k pi/2 + (80 pi/Fs) sum_{j<k} fo_j)), rebuilt here from the running sum of fo
+// (fo_sum: over the symbols BEFORE this one; ksym: their number). Checked on 598 gap edges by
+// tests/test_gpu_parity.py::test_many_silence_gaps_signed_zero_rule.
+__device__ __noinline__ double silence_pd(double dr, double di, PrevSums prv, bool dom1, double fo_sum, uint64_t ksym) {
+    const double pr = dom1 ? prv.a + prv.b : prv.a - prv.b, pi = dom1 ? prv.c - prv.d : prv.c + prv.d;
+    const bool dom_zero = (dr == 0.0 && di == 0.0), prev_zero = (pr == 0.0 && pi == 0.0);
+    if (dom_zero == prev_zero) return 0.0;
+    double th = (80.0 * kPi / kFs) * fo_sum;
+    th -= kTwoPi * rint(th / kTwoPi);
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    // multiply by (-/+ j)^k : tone 1 rotates by -pi/2 per symbol, tone 2 by +pi/2
+    const unsigned q = (unsigned)((dom1 ? (4u - (unsigned)(ksym & 3u)) : (unsigned)(ksym & 3u)) & 3u);
+    double er2 = cs, ei2 = sn;
+    if (q == 1u) { er2 = -sn; ei2 = cs; }
+    else if (q == 2u) { er2 = -cs; ei2 = -sn; }
+    else if (q == 3u) { er2 = sn; ei2 = -cs; }
+    double vr = dr, vi = di;
+    if (dom_zero) {                                 // P = S_prev * (-/+ j) * X40_prev
+        const double jr = dom1 ? pi : -pi, ji = dom1 ? -pr : pr;
+        vr = jr * prv.x40c - ji * prv.x40s;
+        vi = jr * prv.x40s + ji * prv.x40c;
+    }
+    const double qr = vr * er2 + vi * ei2;          // v * conj(E)
+    const double qi = vi * er2 - vr * ei2;
+    return (qr < 0.0 && qi < 0.0) ? kPi : 0.0;
+}
+
 }  // namespace
 
 #include "opv_atan2.h"  // kOpvAtanTab (constant-memory image of the table) + host reference routine
@@ -187,6 +224,9 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
     double kc_halfpi = 1.57079632679489661923, kc_32 = 32.0, kc_m1_32 = -1.0 / 32.0, kc_gain = st.afc_alpha * (kSymRate / kTwoPi);
     asm volatile("" : "+v"(kc_tfmax), "+v"(kc_beta), "+v"(kc_alpha), "+v"(kc_fomax), "+v"(kc_eps));
     asm volatile("" : "+v"(kc_halfpi), "+v"(kc_32), "+v"(kc_m1_32), "+v"(kc_gain));
+    const double kc_nfomax = __builtin_canonicalize(-kc_fomax), kc_ntfmax = __builtin_canonicalize(-kc_tfmax);
+    kc_fomax = __builtin_canonicalize(kc_fomax);
+    kc_tfmax = __builtin_canonicalize(kc_tfmax);
     double sx = 1.0, nsg = 1.0;          // +/-1.0 rebuilt per symbol by rewriting the high word only
     asm volatile("" : "+v"(sx), "+v"(nsg));
 
@@ -384,8 +424,8 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             __builtin_amdgcn_sched_barrier(0);
             q1 = dpp_add<0x122>(q1);
             __builtin_amdgcn_sched_barrier(0);
-            const double fo_sum_next = fo_sum + fo;                 // sum of the fo every symbol USED
-            asm volatile("" : "+v"(fo_sum), "+v"(fo));
+            double fo_sum_next = fo_sum + fo;                       // sum of the fo every symbol USED
+            asm volatile("" : "+v"(fo_sum_next));
             __builtin_amdgcn_sched_barrier(0);
             q1 = dpp_add<0x121>(q1);
             __builtin_amdgcn_sched_barrier(0);
@@ -504,7 +544,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             __builtin_amdgcn_sched_barrier(0);
 
             // ---- timing loop, soft log, next symbol's taps ------------------------------------------
-            tf = clampd(fma(kc_beta, ted, tf), -kc_tfmax, kc_tfmax);  // beta (ref :118,:283-284)
+            tf = clampd(fma(kc_beta, ted, tf), kc_ntfmax, kc_tfmax);  // beta (ref :118,:283-284)
             const double adj = clampd(fma(kc_alpha, ted, tf), -2.0, 2.0);  // alpha (ref :117,:285-286)
             pos += 40.0 + adj;                                      // ref :313
             fetch_addr(pos, false);                                 // pos >= 38 after any symbol
@@ -535,48 +575,10 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 pd = fma(sx, pd, pd_off);
                 pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));  // sign of cy
 
-                if (__builtin_expect(uni_eq(mx, 0.0), 0)) {
-                    // Digital silence on either side. The reference's product (ref :299) is then
-                    // an exact zero whose SIGNS decide std::arg: atan2(+0,-0) = pi, everything
-                    // else +/-0 (IEEE). Working the signs through its complex multiply:
-                    //   dom == (+0,+0), prev != 0 : pi iff Re(prev) < 0 and Im(prev) < 0
-                    //   prev == (+0,+0), dom != 0 : pi iff Re(dom)  < 0 and Im(dom)  < 0
-                    //   both zero                  : 0
-                    // where dom/prev are the reference's correlations, i.e. ours times the
-                    // absolute LO phasor it carries: c_t(k) = S_t(k) conj(E_t(k)),
-                    // prev_t = P_t conj(E_t(k)), P_t = S_t(k-1) (-/+ j) X40(k-1),
-                    // E_t(k) = exp(j(-/+ k pi/2 + (80 pi/Fs) sum_{j<k} fo_j)).
-                    // Rare and wave-uniform; rebuilt here from the running sum of fo.
-                    const bool dom1 = soft < 0.0;
-                    const double pr = dom1 ? prv.a + prv.b : prv.a - prv.b, pi = dom1 ? prv.c - prv.d : prv.c + prv.d;
-                    const bool dom_zero = (dr == 0.0 && di == 0.0), prev_zero = (pr == 0.0 && pi == 0.0);
-                    pd = 0.0;
-                    if (dom_zero != prev_zero) {
-                        const uint32_t nsym_call = ((my_soft_off - soft_off0) & soft_bmask) >> 3;
-                        const uint64_t ksym = n_soft + nsym_call;       // symbols before this one
-                        double th = (80.0 * kPi / kFs) * fo_sum;
-                        th -= kTwoPi * rint(th / kTwoPi);
-                        double sn, cs;
-                        sincos(th, &sn, &cs);
-                        // multiply by (-/+ j)^k : tone 1 rotates by -pi/2 per symbol, tone 2 by +pi/2
-                        const unsigned q = (unsigned)((dom1 ? (4u - (unsigned)(ksym & 3u)) : (unsigned)(ksym & 3u)) & 3u);
-                        double er2 = cs, ei2 = sn;
-                        if (q == 1u) { er2 = -sn; ei2 = cs; }
-                        else if (q == 2u) { er2 = -cs; ei2 = -sn; }
-                        else if (q == 3u) { er2 = sn; ei2 = -cs; }
-                        double vr = dr, vi = di;
-                        if (dom_zero) {                                 // P = S_prev * (-/+ j) * X40_prev
-                            const double jr = dom1 ? pi : -pi, ji = dom1 ? -pr : pr;
-                            vr = jr * prv.x40c - ji * prv.x40s;
-                            vi = jr * prv.x40s + ji * prv.x40c;
-                        }
-                        const double qr = vr * er2 + vi * ei2;          // v * conj(E)
-                        const double qi = vi * er2 - vr * ei2;
-                        if (qr < 0.0 && qi < 0.0) pd = kPi;
-                    }
-                }
+                if (__builtin_expect(uni_eq(mx, 0.0), 0))           // digital silence on either side
+                    pd = silence_pd(dr, di, prv, soft < 0.0, fo_sum, n_soft + (((my_soft_off - soft_off0) & soft_bmask) >> 3));
             }
-            if constexpr (!kFirst) fo = clampd(fma(kc_gain, pd, fo), -kc_fomax, kc_fomax);  // ref :300-303
+            if constexpr (!kFirst) fo = clampd(fma(kc_gain, pd, fo), kc_nfomax, kc_fomax);  // ref :300-303
             fo_sum = fo_sum_next;                                   // (the silence rule above needs the sum BEFORE this symbol)
             // prev <- this symbol's on-time correlations (ref :309-310)
             cur.a = P1o; cur.b = P2o; cur.c = P3o; cur.d = P4o;
