@@ -429,11 +429,16 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             __builtin_amdgcn_sched_barrier(0);
             q1 = dpp_add<0x121>(q1);
             __builtin_amdgcn_sched_barrier(0);
-            const double P1o = readlane_d(q1, 0), P3o = readlane_d(q1, 32);
+            // (a v_readlane result may not be read by the next instructions: the values used first are read first)
             double P2o = readlane_d(q1, 16), P4o = readlane_d(q1, 48);
+            const double P1o = readlane_d(q1, 0), P3o = readlane_d(q1, 32);
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("" : "+v"(P2o), "+v"(P4o));                // one scalar source per instruction: these two in VGPRs
             __builtin_amdgcn_sched_barrier(0);
 
+            // (kept as a difference of the two energies like the reference: the closed form
+            // 4 (P3 P4 - P1 P2) is three instructions instead of nine, but on inputs where the two
+            // tones tie - DC, a bare carrier - it breaks the tie differently from the reference)
             const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;        // S_1 (tone -13550)
             const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;        // S_2 (tone +13550)
             const double en1 = fma(s1r_, s1r_, s1i_ * s1i_);        // ref :264-265
@@ -508,7 +513,8 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 mx = fmax(ax, ay);
                 mn = fmin(ax, ay);
             }
-            const double Ere = readlane_d(q2, 0), Eim = readlane_d(q2, 16), Lre = readlane_d(q2, 32), Lim = readlane_d(q2, 48);
+            const double Eim = readlane_d(q2, 16), Lim = readlane_d(q2, 48);
+            const double Ere = readlane_d(q2, 0), Lre = readlane_d(q2, 32);
             __builtin_amdgcn_sched_barrier(0);
             const double ee = fma(Ere, Ere, Eim * Eim), el = fma(Lre, Lre, Lim * Lim);
             const double num = el - ee, den = el + ee + kc_eps;     // ted = num/den (ref :275/:279)
