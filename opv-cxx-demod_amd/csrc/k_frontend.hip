@@ -31,16 +31,20 @@
 //     previous on-time correlation is advanced by the LO rotation of one symbol,
 //     P_t = S_t * (-/+ j) * X[40]  (T_t[40] = -/+ j exactly), so that
 //     arg(c(k) conj(c(k-1))) = arg(S(k) conj(P(k-1))).
-//   * 12 real sums are reduced over the wave with v_permlane32_swap / v_permlane16_swap
-//     (reduce-scatter, 2 steps) + DPP row rotations, then broadcast through LDS; the scalar
-//     loop filters run redundantly on all lanes (wave-uniform, no divergence).
+//   * Sums over the wave: v_permlane32_swap / v_permlane16_swap (reduce-scatter, 2 steps) + DPP
+//     row rotations, result handed to every lane by v_readlane (no LDS scratch). The on-time gate
+//     goes first (4 values); it decides the soft value and the dominant tone, and only THEN do the
+//     lanes form their early/late products - for the dominant tone alone, so the second reduction
+//     also carries 4 values instead of 8. The scalar loop filters run redundantly on all lanes
+//     (wave-uniform, no divergence).
 //   * A LONE wave on a SIMD issues one instruction of ANY kind (VALU, SALU, LDS, s_nop, branch)
 //     every ~4.7 cycles and gains nothing from independent chains (scripts/microbench): the
 //     symbol rate is set by the instruction COUNT of the loop body. Hence: no per-symbol
-//     bookkeeping (chunk end and tile events are tested only when a conservative symbol budget
-//     `cnt` runs out), stateless power-of-two ring addressing, sign choices folded into FMA
-//     multipliers, one shared reciprocal for the two divides, the first-symbol AFC exception
-//     expressed as a zero loop gain.
+//     bookkeeping (chunk end and tile events are tested once per batch of symbols that provably
+//     need neither), stateless power-of-two ring addressing, sign choices folded into FMA
+//     multipliers and bit-field inserts, one shared reciprocal for the two divides, symbols
+//     processed in pairs with alternating "previous" registers, the first symbol of a call (no
+//     AFC) as its own instantiation, hazard slots of swaps / DPP reads filled with useful work.
 //   * int16 IQ is staged HBM -> LDS in 2048-sample tiles (8 KiB) with direct-to-LDS 16-byte
 //     loads (global_load_lds_dwordx4, 1 KiB per wave instruction), two tile slots forming a
 //     4096-sample ring (slot = sample index & 4095) plus a 4-sample guard that mirrors the head
