@@ -230,6 +230,23 @@ def test_short_and_ragged_inputs(amd, oracle, iq10):
     d.close()
 
 
+def test_every_tail_length_uses_its_last_samples(amd, oracle, iq10):
+    """45 consecutive capture lengths (all residues mod 4 and mod 40): for some of them the last
+    symbol's late gate interpolates on the capture's very last sample, which sits in an incomplete
+    16-byte piece of the last LDS tile (k_frontend copies that piece sample by sample and never reads
+    past n_avail). Batch and streaming."""
+    for streaming in (True, False):
+        for n in range(91003, 91048):
+            d = amd.Demod(1, max_samples=100000, streaming=streaming)
+            got = d.receive([iq10[: 2 * n]])[0]
+            d.close()
+            exp = oracle.receive(iq10[: 2 * n], streaming=streaming)
+            assert got["state"].total_symbols == exp["n_soft"], (streaming, n)
+            a, _ = soft_err(got["soft"], exp["soft"])
+            assert a < SOFT_TIGHT, (streaming, n, a)
+            assert np.allclose(got["chunks"], exp["chunks"], rtol=0, atol=1e-9), (streaming, n)
+
+
 def test_errors_are_loud(amd):
     with pytest.raises(amd.OpvError):
         amd.Demod(0)
