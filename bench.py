@@ -267,7 +267,7 @@ def main():
         one.close()
         # throughput-bound regime: many short streams carved out of the resident captures
         sweep = {}
-        for ns, nfr in ((256, 240), (1024, 60), (2048, 30)):
+        for ns, nfr in ((256, 240), (512, 120), (1024, 60), (2048, 30)):
             if nfr > F:
                 continue
             per = F // nfr

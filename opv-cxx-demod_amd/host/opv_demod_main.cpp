@@ -203,7 +203,7 @@ int main(int argc, char** argv) {
             fprintf(stderr, "  -q          Quiet mode\n");
             fprintf(stderr, "  -r          Raw output to stdout\n");
             fprintf(stderr, "  -s          Streaming mode (for live PlutoSDR input)\n");
-            fprintf(stderr, "  -c          Coherent mode (not available in the MI355X build)\n");
+            fprintf(stderr, "  -c          Coherent mode (batch only in the reference; not provided here, see DESIGN.md)\n");
             fprintf(stderr, "  -a <bw>     AFC bandwidth (default: 0.001)\n");
             fprintf(stderr, "  -o <hz>     Initial frequency offset (streaming mode)\n");
             fprintf(stderr, "  -p <hz>     PLL bandwidth (coherent only; ignored)\n");
@@ -213,13 +213,20 @@ int main(int argc, char** argv) {
             return 0;
         }
     }
-    if (o.coherent) {
-        fprintf(stderr, "opv-demod: coherent mode (-c) is outside the MI355X hot path (SURVEY.md §2 #9); use the non-coherent default\n");
+    // -c: the reference honours it in batch mode only (:1144); with -s it merely changes the banner
+    // (:983-984) and the non-coherent streaming path runs (:995-1125). The batch Costas loop itself is
+    // not provided: it never locks and its trajectory is chaotic (1e-15 rad -> O(1) within 5 frames,
+    // tests/test_oracle_golden.py::test_coherent_loop_is_chaotic), so no implementation that is not
+    // arithmetic-identical to the reference, libm included, can reproduce its output.
+    if (o.coherent && !o.streaming) {
+        fprintf(stderr, "opv-demod: batch coherent mode (-c) is not provided by the MI355X build (DESIGN.md §7); "
+                        "use the non-coherent default\n");
         return 2;
     }
     if (!o.quiet) {  // ref :981-990
         fprintf(stderr, "╔═══════════════════════════════════════════════════════════════════╗\n");
-        if (o.streaming) fprintf(stderr, "║       OPV MSK Demodulator with AFC v1.0 (streaming)              ║\n");
+        if (o.coherent) fprintf(stderr, "║       OPV MSK Demodulator with Costas Loop v1.0 (coherent)       ║\n");
+        else if (o.streaming) fprintf(stderr, "║       OPV MSK Demodulator with AFC v1.0 (streaming)              ║\n");
         else fprintf(stderr, "║           OPV MSK Demodulator with AFC v1.0                       ║\n");
         fprintf(stderr, "╚═══════════════════════════════════════════════════════════════════╝\n\n");
     }

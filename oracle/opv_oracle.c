@@ -306,6 +306,84 @@ size_t oro_demodulate(oro_demod* d, const int16_t* iq, size_t n, double* soft, s
     return ns;
 }
 
+/* ------------------------- coherent demodulator (ref:365-572) ----------------------- */
+void oro_coh_init(oro_coh* d) { /* ref:367-376 */
+    memset(d, 0, sizeof(*d));
+    d->afc_alpha = 0.001;
+    d->pll_alpha = 0.01;
+    d->pll_beta = 0.001;
+}
+
+void oro_coh_set_pll_bandwidth(oro_coh* d, double bw) { /* ref:551-558 */
+    const double wn = bw * TWO_PI;
+    const double zeta = 0.707;
+    d->pll_alpha = 2.0 * zeta * wn / SYM_RATE;
+    d->pll_beta = wn * wn / (SYM_RATE * SYM_RATE);
+}
+
+/* ref:455-543. Fixed 40-sample symbol grid from sample 0 (no timing recovery); every sample is
+ * de-rotated by the carrier phase, which advances by loop_freq per SAMPLE; std::complex
+ * products are written out in the (ac-bd, ad+bc) order libstdc++ evaluates them in. */
+size_t oro_coh_demodulate(oro_coh* d, const int16_t* iq, size_t n, double* soft, size_t cap,
+                          double* extra, size_t cap_extra) {
+    double inc1 = TWO_PI * (-FDEV + d->freq_offset) / FS; /* ref:459 */
+    double inc2 = TWO_PI * (+FDEV + d->freq_offset) / FS; /* ref:460 */
+    const size_t nsym = n / ORO_SPS;                      /* ref:462 */
+    for (size_t sym = 0; sym < nsym; ++sym) {
+        double c1r = 0, c1i = 0, c2r = 0, c2i = 0;
+        for (size_t i = 0; i < ORO_SPS; ++i) {
+            const size_t k = sym * ORO_SPS + i;
+            const double sr = iq[2 * k], si = iq[2 * k + 1];
+            const double rr = cos(d->carrier_phase), ri = -sin(d->carrier_phase); /* ref:470 */
+            const double xr = sr * rr - si * ri;          /* ref:471 corrected = s * phase_rot */
+            const double xi = sr * ri + si * rr;
+            const double k1 = cos(d->phase_f1), s1 = sin(d->phase_f1);            /* ref:474-475 */
+            const double k2 = cos(d->phase_f2), s2 = sin(d->phase_f2);
+            c1r += xr * k1 - xi * (-s1);  c1i += xr * (-s1) + xi * k1;            /* ref:477-478 */
+            c2r += xr * k2 - xi * (-s2);  c2i += xr * (-s2) + xi * k2;
+            d->phase_f1 += inc1;                          /* ref:480-481 */
+            d->phase_f2 += inc2;
+            d->carrier_phase += d->loop_freq;             /* ref:484 */
+        }
+        while (d->phase_f1 > ORO_PI) d->phase_f1 -= TWO_PI;          /* ref:488-493 */
+        while (d->phase_f1 < -ORO_PI) d->phase_f1 += TWO_PI;
+        while (d->phase_f2 > ORO_PI) d->phase_f2 -= TWO_PI;
+        while (d->phase_f2 < -ORO_PI) d->phase_f2 += TWO_PI;
+        while (d->carrier_phase > ORO_PI) d->carrier_phase -= TWO_PI;
+        while (d->carrier_phase < -ORO_PI) d->carrier_phase += TWO_PI;
+
+        const double en1 = c1r * c1r + c1i * c1i;         /* ref:496-497 */
+        const double en2 = c2r * c2r + c2i * c2i;
+        if (soft && sym < cap) soft[sym] = c2r - c1r;     /* ref:502-507 */
+
+        double dr, di;                                    /* ref:512 */
+        if (en1 > en2) { dr = c1r; di = c1i; } else { dr = c2r; di = c2i; }
+        const double mag = hypot(dr, di);                 /* ref:515 std::abs */
+        double pe = 0;
+        if (mag > 1e-10) pe = di / mag;                   /* ref:517-522 */
+        d->loop_freq += d->pll_beta * pe;                 /* ref:526-527 */
+        d->carrier_phase += d->pll_alpha * pe;
+        d->loop_freq = clampd(d->loop_freq, -0.1, 0.1);   /* ref:530 */
+
+        if (sym > 0) {                                    /* ref:535-543 */
+            const double zr = dr * d->prev_re - di * (-d->prev_im);
+            const double zi = dr * (-d->prev_im) + di * d->prev_re;
+            const double pd = atan2(zi, zr);
+            const double ferr = pd * SYM_RATE / TWO_PI;
+            d->freq_offset += d->afc_alpha * ferr;
+            d->freq_offset = clampd(d->freq_offset, -2000.0, 2000.0);
+            inc1 = TWO_PI * (-FDEV + d->freq_offset) / FS;
+            inc2 = TWO_PI * (+FDEV + d->freq_offset) / FS;
+        }
+        d->prev_re = dr; d->prev_im = di;                 /* ref:545 */
+        if (extra && sym < cap_extra) {
+            extra[3 * sym] = d->carrier_phase; extra[3 * sym + 1] = d->loop_freq;
+            extra[3 * sym + 2] = d->freq_offset;
+        }
+    }
+    return nsym;
+}
+
 /* ref:591-607 */
 void oro_tracker_init(oro_tracker* t) {
     memset(t, 0, sizeof(*t));
@@ -579,7 +657,18 @@ int oro_receive(const int16_t* iq, size_t n_samples, const oro_rx_cfg* cfg, oro_
         double* own = NULL;
         if (!tmp) { own = (double*)malloc(cap * sizeof(double)); tmp = own; }
         if (!tmp) return -1;
-        const size_t ns = oro_demodulate(&dm, iq, n_samples, tmp, cap);
+        size_t ns;
+        if (cfg->coherent) {                                           /* ref:1144-1161 */
+            oro_coh cd;
+            oro_coh_init(&cd);
+            cd.freq_offset = out->est_offset;
+            cd.afc_alpha = cfg->afc_alpha;
+            oro_coh_set_pll_bandwidth(&cd, cfg->pll_bw);
+            ns = oro_coh_demodulate(&cd, iq, n_samples, tmp, cap, NULL, 0);
+            dm.freq_offset = cd.freq_offset;                           /* final_offset, ref:1161 */
+        } else {
+            ns = oro_demodulate(&dm, iq, n_samples, tmp, cap);
+        }
         note_chunk(out, &dm, ns);
         feed_symbols(&sink, tmp, ns); /* when tmp == out->soft the tap copy is onto itself */
         free(own);

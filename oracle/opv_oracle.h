@@ -73,6 +73,22 @@ double oro_estimate_offset(const int16_t* iq, size_t n, double* energies);   /* 
 size_t oro_demodulate(oro_demod* d, const int16_t* iq, size_t n,
                       double* soft, size_t cap);                              /* :206-329 */
 
+/* Coherent (Costas-loop) demodulator, `opv-demod -c`, batch mode only (ref:365-572). */
+typedef struct {
+    double freq_offset;        /* :562 */
+    double carrier_phase;      /* :563 */
+    double phase_f1, phase_f2; /* :564 */
+    double loop_freq;          /* :565  rad/sample */
+    double prev_re, prev_im;   /* :566  prev_dominant_ */
+    double afc_alpha;          /* :567 */
+    double pll_alpha, pll_beta;/* :568-569 */
+} oro_coh;
+void   oro_coh_init(oro_coh* d);                                              /* :367-376 */
+void   oro_coh_set_pll_bandwidth(oro_coh* d, double bw_hz);                   /* :551-558 */
+/* extra[3*k..] (optional, cap_extra symbols): carrier_phase, loop_freq, freq_offset AFTER symbol k */
+size_t oro_coh_demodulate(oro_coh* d, const int16_t* iq, size_t n, double* soft, size_t cap,
+                          double* extra, size_t cap_extra);                   /* :455-543 */
+
 enum { ORO_HUNTING = 0, ORO_VERIFYING = 1, ORO_LOCKED = 2 };                  /* :73      */
 enum { /* event kinds, one per stderr line of SyncTracker::process */
     ORO_EV_HUNT_TO_VERIFY = 1, /* :651 */
@@ -119,6 +135,8 @@ typedef struct {
     int have_init_offset; /* -o */
     double init_offset;
     double afc_alpha;     /* -a, default 0.001 */
+    int coherent;         /* -c: honoured in batch mode only (ref:1144; the -s path never looks at it) */
+    double pll_bw;        /* -p, default 50.0 (ref:946) */
 } oro_rx_cfg;
 
 typedef struct {

@@ -8,6 +8,7 @@
 //   (2) pin oracle/opv_oracle.c bit-for-bit while /root/reference is present.
 //
 // Classes reached (reference file:line): MSKDemodulatorAFC src/opv-demod.cpp:108-348,
+// CoherentMSKDemodulator :365-572,
 // SyncTracker :587-787, deinterleave_addr :792-795, ViterbiDecoder :800-847,
 // FrameDecoder :852-902.
 #include <algorithm>
@@ -83,6 +84,26 @@ size_t ref_demod_demodulate(void* h, const int16_t* iq, size_t n, double* soft, 
     auto v = widen(iq, n);
     std::vector<double> s;
     static_cast<MSKDemodulatorAFC*>(h)->demodulate(v.data(), v.size(), s);
+    size_t m = s.size() < cap ? s.size() : cap;
+    if (soft && m) memcpy(soft, s.data(), m * sizeof(double));
+    return s.size();
+}
+
+// ---- CoherentMSKDemodulator (src/opv-demod.cpp:365-572) ---------------------------------
+void* ref_coh_create() { return new CoherentMSKDemodulator(); }
+void ref_coh_destroy(void* h) { delete static_cast<CoherentMSKDemodulator*>(h); }
+void ref_coh_set_freq_offset(void* h, double hz) { static_cast<CoherentMSKDemodulator*>(h)->set_freq_offset(hz); }
+void ref_coh_set_afc(void* h, double a) { static_cast<CoherentMSKDemodulator*>(h)->set_afc_bandwidth(a); }
+void ref_coh_set_pll(void* h, double bw) { static_cast<CoherentMSKDemodulator*>(h)->set_pll_bandwidth(bw); }
+double ref_coh_freq_offset(void* h) { return static_cast<CoherentMSKDemodulator*>(h)->get_freq_offset(); }
+double ref_coh_estimate_offset(void* h, const int16_t* iq, size_t n) {
+    auto v = widen(iq, n);
+    return static_cast<CoherentMSKDemodulator*>(h)->estimate_offset(v.data(), v.size());
+}
+size_t ref_coh_demodulate(void* h, const int16_t* iq, size_t n, double* soft, size_t cap) {
+    auto v = widen(iq, n);
+    std::vector<double> s;
+    static_cast<CoherentMSKDemodulator*>(h)->demodulate(v.data(), v.size(), s);
     size_t m = s.size() < cap ? s.size() : cap;
     if (soft && m) memcpy(soft, s.data(), m * sizeof(double));
     return s.size();

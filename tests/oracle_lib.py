@@ -38,7 +38,7 @@ def build_oracle():
 
 class _RxCfg(C.Structure):
     _fields_ = [("streaming", C.c_int), ("have_init_offset", C.c_int), ("init_offset", C.c_double),
-                ("afc_alpha", C.c_double)]
+                ("afc_alpha", C.c_double), ("coherent", C.c_int), ("pll_bw", C.c_double)]
 
 
 class _RxOut(C.Structure):
@@ -61,6 +61,13 @@ class _Demod(C.Structure):
                 ("prev2_im", C.c_double), ("afc_alpha", C.c_double), ("mu", C.c_double),
                 ("timing_freq", C.c_double), ("alpha_timing", C.c_double), ("beta_timing", C.c_double),
                 ("leftover", C.c_size_t)]
+
+
+class _Coh(C.Structure):
+    _fields_ = [("freq_offset", C.c_double), ("carrier_phase", C.c_double), ("phase_f1", C.c_double),
+                ("phase_f2", C.c_double), ("loop_freq", C.c_double), ("prev_re", C.c_double),
+                ("prev_im", C.c_double), ("afc_alpha", C.c_double), ("pll_alpha", C.c_double),
+                ("pll_beta", C.c_double)]
 
 
 def _iq(a):
@@ -147,6 +154,24 @@ class Oracle:
         ns = self.lib.oro_demodulate(C.byref(d), iq.ctypes.data, n, soft.ctypes.data, soft.size)
         return soft[:ns].copy()
 
+    def coherent_demodulate(self, iq, freq_offset, afc_alpha=0.001, pll_bw=50.0, extra=False, carrier_phase0=0.0):
+        """CoherentMSKDemodulator::demodulate from a fresh object (ref:455-543)."""
+        iq = _iq(iq)
+        n = iq.size // 2
+        d = _Coh()
+        self.lib.oro_coh_init(C.byref(d))
+        d.freq_offset = freq_offset
+        d.afc_alpha = afc_alpha
+        d.carrier_phase = carrier_phase0
+        self.lib.oro_coh_set_pll_bandwidth(C.byref(d), C.c_double(pll_bw))
+        soft = np.empty(n // SPS + 1, np.float64)
+        ex = np.zeros((n // SPS + 1, 3), np.float64)
+        self.lib.oro_coh_demodulate.restype = C.c_size_t
+        ns = self.lib.oro_coh_demodulate(C.byref(d), C.c_void_p(iq.ctypes.data), C.c_size_t(n),
+                                         C.c_void_p(soft.ctypes.data), C.c_size_t(soft.size),
+                                         C.c_void_p(ex.ctypes.data), C.c_size_t(len(ex) if extra else 0))
+        return (soft[:ns].copy(), d, ex[:ns].copy()) if extra else (soft[:ns].copy(), d)
+
     def deinterleave_perm(self):
         return np.array([self.lib.oro_deinterleave_addr(i) for i in range(CODED_BITS)], np.uint16)
 
@@ -168,7 +193,8 @@ class Oracle:
         return dict(metric=m, frame=out, q=q, deint=de, bits=bits)
 
     # ---- whole receiver ----
-    def receive(self, iq, streaming=True, init_offset=None, afc_alpha=0.001, want_soft=True):
+    def receive(self, iq, streaming=True, init_offset=None, afc_alpha=0.001, want_soft=True,
+                coherent=False, pll_bw=50.0):
         iq = _iq(iq)
         n = iq.size // 2
         cap_frames = n // (FRAME_SYMBOLS * 38) + 8
@@ -181,7 +207,8 @@ class Oracle:
         events = np.zeros(4 * cap_frames + 64, EVENT_DTYPE)
         cap_chunks = n // 80000 + 4
         chunks = np.zeros((cap_chunks, 5), np.float64)
-        cfg = _RxCfg(int(streaming), int(init_offset is not None), float(init_offset or 0.0), afc_alpha)
+        cfg = _RxCfg(int(streaming), int(init_offset is not None), float(init_offset or 0.0), afc_alpha,
+                     int(coherent), float(pll_bw))
         out = _RxOut()
         out.frames, out.metrics, out.quality, out.frame_sym = (frames.ctypes.data, metrics.ctypes.data,
                                                                quality.ctypes.data, fsym.ctypes.data)
@@ -234,11 +261,13 @@ class Reference:
     def __init__(self):
         self.lib = C.CDLL(str(ORACLE_DIR / "_ref" / "libopv_ref.so"))
         L = self.lib
-        for f in ("ref_demod_create", "ref_tracker_create"):
+        for f in ("ref_demod_create", "ref_tracker_create", "ref_coh_create"):
             getattr(L, f).restype = C.c_void_p
-        for f in ("ref_demod_freq_offset", "ref_demod_timing_freq", "ref_demod_estimate_offset"):
+        for f in ("ref_demod_freq_offset", "ref_demod_timing_freq", "ref_demod_estimate_offset",
+                  "ref_coh_freq_offset", "ref_coh_estimate_offset"):
             getattr(L, f).restype = C.c_double
-        for f in ("ref_demod_leftover", "ref_demod_demodulate", "ref_deinterleave_addr", "ref_log_take"):
+        for f in ("ref_demod_leftover", "ref_demod_demodulate", "ref_deinterleave_addr", "ref_log_take",
+                  "ref_coh_demodulate"):
             getattr(L, f).restype = C.c_size_t
         L.ref_demod_destroy.argtypes = [C.c_void_p]
         L.ref_demod_set_freq_offset.argtypes = [C.c_void_p, C.c_double]
@@ -249,6 +278,13 @@ class Reference:
         L.ref_demod_estimate_offset.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.ref_demod_demodulate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.ref_tracker_destroy.argtypes = [C.c_void_p]
+        L.ref_coh_destroy.argtypes = [C.c_void_p]
+        L.ref_coh_set_freq_offset.argtypes = [C.c_void_p, C.c_double]
+        L.ref_coh_set_afc.argtypes = [C.c_void_p, C.c_double]
+        L.ref_coh_set_pll.argtypes = [C.c_void_p, C.c_double]
+        L.ref_coh_freq_offset.argtypes = [C.c_void_p]
+        L.ref_coh_estimate_offset.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.ref_coh_demodulate.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.ref_tracker_state.argtypes = [C.c_void_p]
         L.ref_tracker_process.argtypes = [C.c_void_p, C.c_double, C.c_size_t, C.c_void_p, C.c_void_p]
         L.ref_deinterleave_addr.argtypes = [C.c_size_t]
@@ -283,9 +319,9 @@ class Reference:
     def deinterleave_perm(self):
         return np.array([self.lib.ref_deinterleave_addr(i) for i in range(CODED_BITS)], np.uint16)
 
-    def receive(self, iq, streaming=True, init_offset=None, afc_alpha=0.001):
+    def receive(self, iq, streaming=True, init_offset=None, afc_alpha=0.001, coherent=False, pll_bw=50.0):
         """Drive the reference classes the way the reference's main() does
-        (streaming src/opv-demod.cpp:995-1113, batch :1132-1206)."""
+        (streaming src/opv-demod.cpp:995-1113, batch :1132-1206, -c :1144-1161)."""
         iq = _iq(iq)
         n = iq.size // 2
         L = self.lib
@@ -338,6 +374,20 @@ class Reference:
                 s = demod(iq[2 * start:])
                 softs.append(s)
                 feed(s)
+        elif coherent:
+            cd = L.ref_coh_create()
+            est = L.ref_coh_estimate_offset(cd, iq.ctypes.data, n)
+            L.ref_coh_set_freq_offset(cd, est)
+            L.ref_coh_set_afc(cd, afc_alpha)
+            L.ref_coh_set_pll(cd, pll_bw)
+            buf = np.empty(n // SPS + 1, np.float64)
+            ns = L.ref_coh_demodulate(cd, iq.ctypes.data, n, buf.ctypes.data, buf.size)
+            L.ref_demod_set_freq_offset(dm, L.ref_coh_freq_offset(cd))  # so final_freq_offset below reports it
+            chunks.append([L.ref_coh_freq_offset(cd), 0.0, float("nan"), 0.0, float(ns)])
+            L.ref_coh_destroy(cd)
+            s = buf[:ns].copy()
+            softs.append(s)
+            feed(s)
         else:
             est = L.ref_demod_estimate_offset(dm, iq.ctypes.data, n)
             L.ref_demod_set_freq_offset(dm, est)

@@ -7,6 +7,7 @@ scale-normalised error and report the measured value.
 """
 import hashlib
 import os
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -15,6 +16,7 @@ from amd_lib import load
 from oracle_lib import CODED_BITS, FRAME_BYTES, Oracle, format_events, impair
 
 pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
 
 SOFT_RTOL = 1e-5      # contract (BASELINE.json north_star)
 SOFT_TIGHT = 1e-9     # what fp64 re-association actually leaves (SURVEY.md §7-3 measured 6e-12)
@@ -650,3 +652,25 @@ def test_many_silence_gaps_signed_zero_rule(amd, oracle, iq10):
             assert done.size >= 10
         for c in done:
             assert np.allclose(g["chunks"][c], exp["chunks"][c], rtol=0, atol=1e-7), (c, g["chunks"][c], exp["chunks"][c])
+
+
+def test_host_cli_process_contract(amd, golden, iq10):
+    """bin/opv-demod is a drop-in for the reference binary on BASELINE configs[0]: same stdout bytes, same
+    stderr TEXT (banner, offset line, tracker lines, frame boxes, summary), same exit status; `-s -c`
+    only swaps the banner (reference :983-984, the -s path ignores -c); batch `-c` is refused loudly."""
+    import subprocess
+    arrays, meta = golden
+    exe = str(ROOT / "opv-cxx-demod_amd" / "bin" / "opv-demod")
+    g = ROOT / "tests" / "golden"
+    raw = iq10.tobytes()
+    for args, frames_key, text in ((["-s", "-r"], "c1_stream_frames", "c1_stream_stderr.txt"),
+                                   (["-r"], "c1_batch_frames", "c1_batch_stderr.txt"),
+                                   (["-s", "-c", "-r"], "c1_stream_frames", "c1_stream_coherent_flag_stderr.txt")):
+        p = subprocess.run([exe] + args, input=raw, capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()[-400:]
+        assert p.stdout == arrays[frames_key].tobytes(), args
+        assert p.stderr.decode("utf-8") == (g / text).read_text(), args
+    p = subprocess.run([exe, "-s", "-r", "-q"], input=raw[: 4 * 50000], capture_output=True, timeout=300)
+    assert p.returncode == 1 and p.stdout == b""                      # no frame decoded -> exit 1 (:1124)
+    p = subprocess.run([exe, "-c", "-r"], input=raw, capture_output=True, timeout=300)
+    assert p.returncode == 2 and p.stdout == b"" and b"coherent" in p.stderr

@@ -145,3 +145,54 @@ def test_live_against_reference_classes(oracle, iq10):
         assert np.array_equal(a["frame_sym"], b["frame_sym"])
         assert format_events(a["events"]) == [ln for ln in b["log"].strip().split("\n") if ln]
     assert oracle.estimate_offset(x) == ref.estimate_offset(x)
+
+
+# ------------------------------------------------------------------ coherent mode (-c), SURVEY §8f-4
+@pytest.mark.parametrize("tag", ["clean", "p700_16dB_pll20"])
+def test_coherent_mode_bit_exact(oracle, iq10, tag):
+    """oracle's restatement of CoherentMSKDemodulator (reference :365-572) and of the -c batch driver
+    (:1144-1161) against tests/golden/coherent.* (made by the compiled reference)."""
+    import json
+    from pathlib import Path
+    g = Path(__file__).parent / "golden"
+    meta = json.loads((g / "coherent.json").read_text())[tag]
+    arrays = np.load(g / "coherent.npz")
+    x = iq10 if tag == "clean" else impair(iq10, 2000.0, 700.0, 16.0, seed=11)
+    assert sha(x) == meta["iq_sha256"]
+    r = oracle.receive(x, streaming=False, coherent=True, pll_bw=meta["pll_bw"])
+    assert np.array_equal(r["soft"], arrays[tag + "_soft"])          # fp64, bit for bit
+    assert np.array_equal(r["frames"], arrays[tag + "_frames"]) and len(r["frames"]) == meta["n_frames"]
+    assert np.array_equal(r["metrics"], arrays[tag + "_metrics"])
+    assert np.array_equal(r["frame_sym"], arrays[tag + "_frame_sym"])
+    assert r["est_offset"] == meta["est_offset"] and r["final_freq_offset"] == meta["final_freq_offset"]
+    assert sha(r["frames"]) == meta["stdout_sha256"]
+    ev = [ln for ln in meta["stderr_lines"] if ln.startswith("[")]
+    assert format_events(r["events"]) == ev
+
+
+def test_coherent_loop_is_chaotic(oracle, iq10):
+    """Why §8f-4 has no GPU row: the reference's Costas loop never locks and its
+    trajectory is chaotic - 1e-15 rad on the initial carrier phase grows to O(1) differences of the soft
+    symbols within ~5 frames, so only arithmetic that is bit-identical to the reference's
+    (libm sin/cos/atan2/hypot results included) can follow it. The same probe on the non-coherent
+    demodulator stays at the 1e-13 level (its loops are contractive)."""
+    est = oracle.estimate_offset(iq10)
+    a, _ = oracle.coherent_demodulate(iq10, est)
+    b, _ = oracle.coherent_demodulate(iq10, est, carrier_phase0=1e-15)
+    e = np.abs(a - b) / np.mean(np.abs(a))
+    assert e[:1000].max() < 1e-10
+    assert e[-5000:].max() > 1e-2
+    d1, d2 = oracle.new_demod(), oracle.new_demod()
+    d1.freq_offset = d2.freq_offset = est
+    d2.mu = 1e-15
+    s1, s2 = oracle.demodulate(d1, iq10), oracle.demodulate(d2, iq10)
+    assert len(s1) == len(s2) and np.max(np.abs(s1 - s2)) / np.mean(np.abs(s1)) < 1e-9
+
+
+@pytest.mark.skipif(not Reference.available(), reason="oracle/_ref/libopv_ref.so not built")
+def test_coherent_live_against_reference_class(oracle, iq10):
+    x = impair(iq10, amp=5000.0, f0_hz=-300.0, ebn0_db=14.0, seed=5)
+    a = oracle.receive(x, streaming=False, coherent=True, pll_bw=35.0, afc_alpha=0.002)
+    b = Reference().receive(x, streaming=False, coherent=True, pll_bw=35.0, afc_alpha=0.002)
+    assert np.array_equal(a["soft"], b["soft"]) and np.array_equal(a["frames"], b["frames"])
+    assert a["final_freq_offset"] == b["final_freq_offset"]
