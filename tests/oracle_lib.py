@@ -433,3 +433,20 @@ def impair(iq, amp=2000.0, f0_hz=0.0, ebn0_db=None, seed=1, full_scale=16383.0):
     out[0::2] = np.clip(np.rint(z.real), -32768, 32767).astype(np.int16)
     out[1::2] = np.clip(np.rint(z.imag), -32768, 32767).astype(np.int16)
     return out
+
+
+def resample_clock(iq, ppm):
+    """Sample-clock error for the timing loop: the capture as an ADC running `ppm`
+    parts per million fast would have taken it (linear interpolation, round to nearest). A test
+    INPUT generator - any int16 stream is a valid input for the parity tests."""
+    iq = _iq(iq)
+    z = iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)
+    n_out = int(z.size / (1.0 + ppm * 1e-6))
+    t = np.arange(n_out, dtype=np.float64) * (1.0 + ppm * 1e-6)
+    i = np.minimum(t.astype(np.int64), z.size - 2)
+    f = t - i
+    y = z[i] * (1.0 - f) + z[i + 1] * f
+    out = np.empty(2 * n_out, np.int16)
+    out[0::2] = np.clip(np.rint(y.real), -32768, 32767).astype(np.int16)
+    out[1::2] = np.clip(np.rint(y.imag), -32768, 32767).astype(np.int16)
+    return out
