@@ -291,6 +291,49 @@ def main():
                                     "frames_released": int(cnt.sum())}
             m.close()
         extras["stream_sweep"] = sweep
+        # PCIe-inclusive: the boundary's host-buffer entry point (opv_push_iq) instead of HBM-resident
+        # captures. Pinned host copies of the first FH frames of every stream are pushed in rounds of RH
+        # frames; opv_push_iq copies on its own HIP stream, so round r+1 crosses PCIe while the
+        # kernels of round r run. Same streams attached in HBM are timed beside it.
+        FH, RH = min(F, 100), 10
+        if FH >= 2 * RH:
+            sub_n = FH * FRAME_SAMPLES
+            host = [d_iq[k][: 2 * sub_n].cpu().pin_memory() for k in range(S)]
+            host_np = [h.numpy() for h in host]
+            hp = amd.Demod(S, max_samples=sub_n + 64, streaming=True, device=local_rank)
+            res = {}
+            for mode in ("hbm_attached", "host_pushed", "host_pushed"):
+                hp.reset()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if mode == "hbm_attached":
+                    for k in range(S):
+                        hp.attach(k, d_iq[k].data_ptr(), sub_n, eof=True)
+                    hp.process()
+                else:
+                    per = RH * FRAME_SAMPLES
+                    for r in range(0, sub_n, per):
+                        m = min(per, sub_n - r)
+                        for k in range(S):
+                            hp.push(k, host_np[k][2 * r: 2 * (r + m)])
+                        hp.process()
+                    for k in range(S):
+                        hp.flush(k)
+                    hp.process()
+                hp.sync()
+                t1 = time.perf_counter() - t0
+                f_, m_, c_, cap_ = hp.device_frames()
+                cnt = torch.as_tensor(DevPtr(c_, (S,), "<i4"), device=dev).cpu().numpy()
+                res[mode] = {"Msamples/s": round(S * sub_n / t1 / 1e6, 1), "ms": round(t1 * 1e3, 2),
+                             "GB/s_over_pcie": None if mode == "hbm_attached" else round(S * sub_n * 4 / t1 / 1e9, 2),
+                             "frames_released": int(cnt.sum())}
+                if mode != "hbm_attached":     # the pushed streams are fresh (reset drops the attachment)
+                    fr_h = torch.as_tensor(DevPtr(f_, (S, cap_, 134), "|u1"), device=dev)[:, : FH - 1, :]
+                    assert bool((fr_h == frames_view[:, : FH - 1, :]).all().item()), "pushed-path frames differ from the attached run"
+            res["config"] = f"{S} streams x {FH} frames, rounds of {RH} frames, pinned host buffers"
+            extras["pcie_inclusive"] = res
+            hp.close()
+            del host, host_np
         out["extras"] = extras
         base = d_base.cpu().numpy()
         out["cpu_baseline"] = cpu_baseline(base.tobytes(), n)

@@ -94,9 +94,16 @@ struct HostStream {
 struct opv_ctx {
     int n_streams = 0;
     opv_cfg cfg{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // kernels, in order
+    hipStream_t copy_stream = nullptr;  // host -> device IQ of opv_push_iq: overlaps the kernels of the previous round
     OpvStream* d_streams = nullptr;
     StreamIn* d_in = nullptr;
+    // per-round stream updates travel through pinned host memory (no host sync in opv_process):
+    // kInSlots rounds may be in flight before the host has to wait for the oldest upload
+    static constexpr int kInSlots = 4;
+    StreamIn* h_in = nullptr;           // kInSlots x n_streams, pinned
+    hipEvent_t in_ev[kInSlots] = {};
+    unsigned round_no = 0;
     std::vector<OpvStream> mirror;  // host copy, refreshed by refresh()
     std::vector<OpvStream> initial; // as created (for reset)
     std::vector<HostStream> hs;
@@ -166,7 +173,10 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
     } while (0)
 
     HIPCHK_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK_C(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     const size_t S = (size_t)n_streams;
+    HIPCHK_C(hipHostMalloc(&c->h_in, sizeof(StreamIn) * S * opv_ctx::kInSlots, hipHostMallocDefault));
+    for (auto& e : c->in_ev) HIPCHK_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK_C(hipMalloc(&c->d_streams, sizeof(OpvStream) * S));
     HIPCHK_C(hipMalloc(&c->d_in, sizeof(StreamIn) * S));
     HIPCHK_C(hipMalloc(&c->d_soft, sizeof(double) * c->cap_soft * S));
@@ -212,7 +222,12 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
 
 extern "C" void opv_destroy(opv_ctx* c) {
     if (!c) return;
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& e : c->in_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& h : c->hs)
         if (h.d_iq_owned) (void)hipFree(h.d_iq_owned);
     for (auto& e : c->ev)
@@ -283,9 +298,12 @@ extern "C" int opv_push_iq(opv_ctx* c, int s, const int16_t* iq, size_t n) {
         HIPCHK(hipMalloc(&h.d_iq_owned, h.iq_cap * 4 + 16384));  // + slack for whole-tile reads
         h.d_iq = h.d_iq_owned;
     }
-    HIPCHK(hipMemcpyAsync(h.d_iq_owned + 2 * h.n_avail, iq, n * 4, hipMemcpyHostToDevice, c->stream));
-    // the caller keeps ownership of `iq`: the copy must have left the host buffer before we return
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // On the copy stream: the kernels of an opv_process still in flight only read samples below the
+    // n_avail they were launched with, so new samples land behind them while they run (H2D over
+    // PCIe overlaps compute). The caller keeps ownership of `iq`: the copy must have left the host
+    // buffer before we return, which is a wait for THIS copy only, not for the kernels.
+    HIPCHK(hipMemcpyAsync(h.d_iq_owned + 2 * h.n_avail, iq, n * 4, hipMemcpyHostToDevice, c->copy_stream));
+    HIPCHK(hipStreamSynchronize(c->copy_stream));
     h.n_avail += n;
     h.dirty = true;
     return OPV_OK;
@@ -318,7 +336,9 @@ extern "C" int opv_process(opv_ctx* c) {
     if (!c) return fail(OPV_EINVAL, "null context");
     HIPCHK(hipSetDevice(c->cfg.device));
     const int S = c->n_streams;
-    std::vector<StreamIn> in(S);
+    const int slot = (int)(c->round_no % opv_ctx::kInSlots);
+    if (c->round_no >= (unsigned)opv_ctx::kInSlots) HIPCHK(hipEventSynchronize(c->in_ev[slot]));  // upload of round_no-kInSlots done
+    StreamIn* in = c->h_in + (size_t)slot * S;
     uint64_t max_new = 0;
     bool any = false;
     for (int i = 0; i < S; ++i) {
@@ -332,9 +352,10 @@ extern "C" int opv_process(opv_ctx* c) {
     }
     if (!any) return OPV_OK;
     c->mirror_valid = false;
-    // pageable memcpy of a small array: staged by the runtime before the call returns
-    HIPCHK(hipMemcpyAsync(c->d_in, in.data(), sizeof(StreamIn) * S, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // pinned -> device, in stream order behind the previous round's kernels; no host wait
+    HIPCHK(hipMemcpyAsync(c->d_in, in, sizeof(StreamIn) * S, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->in_ev[slot], c->stream));
+    ++c->round_no;
     OpvGlobalCfg g{c->cfg.streaming, c->cfg.have_init_offset, c->cfg.init_offset_hz};
     k_apply_inputs<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_in, S);
     const bool tm = c->timing;
