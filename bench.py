@@ -267,7 +267,7 @@ def main():
         one.close()
         # throughput-bound regime: many short streams carved out of the resident captures
         sweep = {}
-        for ns, nfr in ((256, 240), (512, 120), (1024, 60), (2048, 30)):
+        for ns, nfr in ((256, 240), (512, 120), (1024, 60), (2048, 30), (8192, 7)):
             if nfr > F:
                 continue
             per = F // nfr
@@ -275,20 +275,26 @@ def main():
                 continue
             sub_n = nfr * FRAME_SAMPLES
             m = amd.Demod(ns, max_samples=sub_n + 64, streaming=True, device=local_rank)
-            for rep in range(2):
-                m.reset()
-                for j in range(ns):
-                    k, seg = j % S, j // S
-                    m.attach(j, d_iq[k].data_ptr() + 4 * seg * sub_n, sub_n, eof=True)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                m.process()
-                m.sync()
-                t1 = time.perf_counter() - t0
-            f_, m_, c_, cap_ = m.device_frames()
-            cnt = torch.as_tensor(DevPtr(c_, (ns,), "<i4"), device=dev).cpu().numpy()
-            sweep[f"{ns}x{nfr}"] = {"Msamples/s": round(ns * sub_n / t1 / 1e6, 1), "ms": round(t1 * 1e3, 2),
-                                    "frames_released": int(cnt.sum())}
+            ent = {}
+            for spw in (1, 4):                          # streams per wavefront (opv_set_frontend)
+                if spw == 4 and ns < 8192:         # the four-per-wave mapping only pays from ~8k streams
+                    continue
+                m.set_frontend(spw)
+                for rep in range(2):
+                    m.reset()
+                    for j in range(ns):
+                        k, seg = j % S, j // S
+                        m.attach(j, d_iq[k].data_ptr() + 4 * seg * sub_n, sub_n, eof=True)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    m.process()
+                    m.sync()
+                    t1 = time.perf_counter() - t0
+                f_, m_, c_, cap_ = m.device_frames()
+                cnt = torch.as_tensor(DevPtr(c_, (ns,), "<i4"), device=dev).cpu().numpy()
+                ent[f"{spw}_per_wave"] = {"Msamples/s": round(ns * sub_n / t1 / 1e6, 1), "ms": round(t1 * 1e3, 2),
+                                          "frames_released": int(cnt.sum())}
+            sweep[f"{ns}x{nfr}"] = ent
             m.close()
         extras["stream_sweep"] = sweep
         # PCIe-inclusive: the boundary's host-buffer entry point (opv_push_iq) instead of HBM-resident

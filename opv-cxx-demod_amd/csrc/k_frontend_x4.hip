@@ -1,0 +1,420 @@
+// k_frontend_x4.hip — MSK front-end for MANY streams: FOUR IQ streams per wavefront, one per DPP row
+// (16 lanes), four interpolated samples per lane. Same arithmetic contract as k_frontend.hip
+// (reference src/opv-demod.cpp:206-329 + the chunker :1012-1113 / :1132-1173); selected by the shim
+// when a context carries enough streams to fill the chip without the one-wave-per-stream mapping
+// (opv_capi.hip: opv_set_frontend / automatic from 8192 streams).
+//
+// Why: a symbol's loop filters, divides and atan2 are scalar work per STREAM. With one stream per
+// wave they are executed on 64 lanes for one result (about 100 of that kernel's 213 instructions per
+// symbol, plus 58 for two 64-lane reductions). Here a wave instruction advances four streams: the
+// scalar tail is shared by four, the reductions stay inside a DPP row (4 rotations, no cross-row
+// swaps, no v_readlane), and the per-sample work grows only from one to four taps per lane.
+// Measured (rocprofv3 PMC, MI355X): 448 VALU + 87 SALU + 12 LDS/VMEM per wave and symbol = 137 issued
+// instructions per symbol and stream instead of 213. Because a wave now carries four streams, the chip
+// fills four times later: the mapping only overtakes one-wave-per-stream at ~8192 streams per GPU
+// (67 vs 56 GS/s); below that the one-wave kernel, with its shorter per-symbol latency, is the default
+// (DESIGN.md §3.1).
+//
+// Mapping (row r = lane / 16 serves stream 4*blockIdx.x + r, t = lane % 16):
+//   * lane t owns the interpolated samples Lam_j = L(pos + j - 10), j = t + 16 q, q = 0..3 (j < 60); the
+//     three gates are j in [0,40) / [10,50) / [20,60) as in k_frontend.hip, their LO constants T[i] zero
+//     outside the window, so a lane accumulates its (up to) four taps per gate in registers;
+//   * X[m] = exp(j m d) for m = t - 10 by the same polynomial, X[m+16 q] by three complex multiplies
+//     with X[16];
+//   * every stream-level quantity (pos, fo, tf, previous sums, chunk bookkeeping) lives in VGPRs,
+//     replicated over the 16 lanes of its row; rows run their own chunk schedule under exec masks;
+//   * int16 IQ: a 1024-sample ring per row in LDS (+ 64-sample guard mirroring its head), refilled in
+//     64-sample blocks (one direct-to-LDS 16 B/lane load per row and block), requested 320+ samples
+//     before their first use and awaited with one s_waitcnt vmcnt(0) every fourth symbol.
+//
+// Differences from the reference are of the same kind and size as k_frontend.hip's (shared
+// interpolation fraction, factored LO, FMA, table atan2): soft symbols agree to ~1e-14 of their mean,
+// every decision downstream is identical (tests/test_gpu_parity.py runs both mappings).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "opv_device.h"
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;  // ref :43
+constexpr double kTwoPi = 2.0 * kPi;            // ref :44
+constexpr double kFs = 2168000.0;               // ref :40
+constexpr double kSymRate = 2168000.0 / 40.0;   // ref :41
+constexpr double kDeltaPerHz = kTwoPi / kFs;    // d = 2 pi fo / Fs (ref :210-211, :305-306)
+
+constexpr uint32_t kRingSamples = 1024;
+constexpr uint32_t kRingBytes = kRingSamples * 4;   // 4096
+constexpr uint32_t kGuardBytes = 256;               // mirror of the ring's first 64 samples
+constexpr uint32_t kRowBytes = kRingBytes + kGuardBytes;
+constexpr uint32_t kBlock = 64;                     // samples per refill block (16 lanes x 16 B)
+constexpr uint32_t kAheadMin = 544;                 // keep hi >= floor(pos) + this (56 reach + 4 symbols x 42 + 320)
+constexpr uint32_t kTabOff = 4 * kRowBytes;         // 17408
+constexpr uint32_t kTabRow = 10;
+constexpr uint32_t kLdsBytes = kTabOff + 33 * kTabRow * 8;  // 20048 <= 20480: eight workgroups per CU
+static_assert(kTabOff % 16 == 0, "16-byte LDS alignment");
+
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) unsigned char gbyte;
+
+__device__ inline int dlo(double v) { return __double2loint(v); }
+__device__ inline int dhi(double v) { return __double2hiint(v); }
+__device__ inline double mkd(int hi, int lo) { return __hiloint2double(hi, lo); }
+
+template <int CTRL>
+__device__ inline double dpp_add(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(dlo(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(dhi(v), CTRL, 0xF, 0xF, true);
+    return v + mkd(hi, lo);
+}
+// sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8, 4, 2, 1)
+__device__ inline double row_sum(double v) {
+    v = dpp_add<0x128>(v);
+    v = dpp_add<0x124>(v);
+    v = dpp_add<0x122>(v);
+    v = dpp_add<0x121>(v);
+    return v;
+}
+__device__ inline double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+// exp(j x), |x| <= 0.284: same near-minimax pair as k_frontend.hip (abs error 1e-19 / 1.3e-18)
+__device__ inline void expj_small(double x, double& xs, double& xc) {
+    const double u = x * x;
+    double p = fma(-0x1.add325df5e3b5p-26, u, 0x1.71de256e9bdffp-19);
+    double r = fma(-0x1.276f06eab6283p-22, u, 0x1.a019dfaa26924p-16);
+    p = fma(p, u, -0x1.a01a019da51d6p-13);
+    r = fma(r, u, -0x1.6c16c16818f3fp-10);
+    p = fma(p, u, 0x1.1111111110f73p-7);
+    r = fma(r, u, 0x1.5555555555014p-5);
+    p = fma(p, u, -0x1.5555555555555p-3);
+    r = fma(r, u, -0x1.0000000000000p-1);
+    xc = fma(r, u, 1.0);
+    xs = fma(x * u, p, x);
+}
+
+struct PrevSums {
+    double a, b, c, d;  // on-time P1..P4
+    double x40c, x40s;  // X[40] = exp(j 40 d) of that symbol
+};
+
+// std::arg on digital silence (ref :299): see k_frontend.hip::silence_pd for the derivation.
+__device__ __noinline__ double silence_pd_x4(double dr, double di, double pa, double pb, double pc, double pd_, double x40c,
+                                              double x40s, bool dom1, double fo_sum, uint32_t ksym) {
+    const double pr = dom1 ? pa + pb : pa - pb, pi = dom1 ? pc - pd_ : pc + pd_;
+    const bool dom_zero = (dr == 0.0 && di == 0.0), prev_zero = (pr == 0.0 && pi == 0.0);
+    if (dom_zero == prev_zero) return 0.0;
+    double th = (80.0 * kPi / kFs) * fo_sum;
+    th -= kTwoPi * rint(th / kTwoPi);
+    double sn, cs;
+    sincos(th, &sn, &cs);
+    const unsigned q = (unsigned)((dom1 ? (4u - (ksym & 3u)) : (ksym & 3u)) & 3u);
+    double er2 = cs, ei2 = sn;
+    if (q == 1u) { er2 = -sn; ei2 = cs; }
+    else if (q == 2u) { er2 = -cs; ei2 = -sn; }
+    else if (q == 3u) { er2 = sn; ei2 = -cs; }
+    double vr = dr, vi = di;
+    if (dom_zero) {
+        const double jr = dom1 ? pi : -pi, ji = dom1 ? -pr : pr;
+        vr = jr * x40c - ji * x40s;
+        vi = jr * x40s + ji * x40c;
+    }
+    const double qr = vr * er2 + vi * ei2;
+    const double qi = vi * er2 - vr * ei2;
+    return (qr < 0.0 && qi < 0.0) ? kPi : 0.0;
+}
+
+}  // namespace
+
+extern __constant__ double kOpvAtanTab[33][10];  // defined with k_frontend.hip (opv_atan2.h)
+
+extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_x4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
+                                                                    int n_streams) {
+    const int lane = threadIdx.x, row = lane >> 4, t = lane & 15;
+    const int sidx = (int)blockIdx.x * 4 + row;
+    const bool have = sidx < n_streams;
+    OpvStream& st = streams[have ? sidx : n_streams - 1];   // idle rows read a valid record and never write
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
+    double* atab = reinterpret_cast<double*>(lds + kTabOff);
+    for (int i = lane; i < 33 * (int)kTabRow; i += 64) atab[i] = (&kOpvAtanTab[0][0])[i];
+    const unsigned char* ring = lds + (uint32_t)row * kRowBytes;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const uint32_t ring_lds = lds_base + (uint32_t)row * kRowBytes;
+
+    // ---- per-lane constants: T_1[i] = (cos(pi i/80), -sin(pi i/80)) inside each gate's window ----
+    double aE[4], bE[4], aO[4], bO[4], aL[4], bL[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = t + 16 * q;
+        double sn, cs;
+        aE[q] = bE[q] = aO[q] = bO[q] = aL[q] = bL[q] = 0.0;
+        if (j < 40) { sincospi((double)j / 80.0, &sn, &cs); aE[q] = cs; bE[q] = -sn; }
+        if (j >= 10 && j < 50) { sincospi((double)(j - 10) / 80.0, &sn, &cs); aO[q] = cs; bO[q] = -sn; }
+        if (j >= 20 && j < 60) { sincospi((double)(j - 20) / 80.0, &sn, &cs); aL[q] = cs; bL[q] = -sn; }
+    }
+    const double kf0 = (double)(t - 10);
+    const double kfs0 = kf0 * kDeltaPerHz;
+    const double kgain = st.afc_alpha * (kSymRate / kTwoPi);
+
+    // ---- carry (row-uniform, in VGPRs) ----------------------------------------------------------
+    double fo = st.freq_offset, tf = st.timing_freq, mu = st.mu, fo_sum = st.fo_sum;
+    PrevSums pv{st.p1r, st.p1i, st.p2r, st.p2i, st.x40c, st.x40s};
+    uint32_t origin = (uint32_t)st.origin;
+    const uint32_t n_avail = (uint32_t)st.n_avail;
+    uint64_t n_soft = st.n_soft, total_samples = st.total_samples;
+    uint32_t n_chunks = st.n_chunks;
+    int tail_done = st.tail_done, overflow = st.overflow;
+    const int eof = st.eof;
+    const uint64_t cap_soft = st.cap_soft;
+    if (cap_soft > (1ull << 28)) overflow = 1;
+    uint64_t soft_keep = st.trk_next >= 24 ? st.trk_next - 24 : 0;
+    if (st.trk_state != 0 && st.trk_anchor < soft_keep) soft_keep = st.trk_anchor;
+    const uint32_t soft_bmask = (uint32_t)(cap_soft * 8u - 1u) & ~7u;
+    gbyte* const soft_base = (gbyte*)st.soft;
+    const gbyte* const iq_bytes = (const gbyte*)st.iq;
+    const uint64_t n_bytes = (uint64_t)n_avail * 4u;
+    double* const chunk_log = st.chunk_log;
+    const uint32_t cap_chunks = st.cap_chunks;
+
+    // ---- call state ---------------------------------------------------------------------------------
+    bool done = !have, in_call = false, first = false, last = false;
+    uint32_t N = 0, soft_off = 0, soft_off0 = 0;
+    double Nd = 0.0, pos = 0.0;
+
+    // ---- ring refill ------------------------------------------------------------------------------
+    // hi: the row's ring holds absolute samples [hi - 1024, hi) (as far as the capture reaches); blocks
+    // of 64 samples, 256 B aligned in the capture. One direct-to-LDS load per row and block: lane l of
+    // the wave writes LDS byte m0 + 16 l, so the row's destination is passed as m0 = dst - 256 row.
+    auto glds16 = [&](const gbyte* gsrc, uint32_t m0v) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(gsrc), "s"(m0v)
+                     : "memory");
+    };
+    uint32_t hi;
+    {
+        const uint32_t g0 = origin + (uint32_t)(int)mu;
+        hi = (g0 >= 11u ? g0 - 11u : 0u) & ~(kBlock - 1u);
+    }
+    auto issue_block = [&](uint32_t dst_off) {   // the calling lanes are the 16 lanes of ONE row
+        const uint64_t off = (uint64_t)hi * 4u + (uint32_t)t * 16u;
+        const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ring_lds + dst_off - 256u * (uint32_t)row));
+        if (off + 16u <= n_bytes) glds16(iq_bytes + off, m0v);
+        else if (off < n_bytes) {   // the capture's last, incomplete 16 bytes: nothing past n_avail is read
+            for (uint32_t j = 0; off + 4u * j < n_bytes; ++j)
+                *reinterpret_cast<int*>(lds + (uint32_t)row * kRowBytes + dst_off + (uint32_t)t * 16u + 4u * j) =
+                    *reinterpret_cast<const __attribute__((address_space(1))) int*>(iq_bytes + off + 4u * j);
+        }
+    };
+    auto refill = [&](bool wants, uint32_t g, int max_rounds) {
+        for (int rep = 0; rep < max_rounds; ++rep) {
+            const bool need = wants && hi < g + kAheadMin && (uint64_t)hi * 4u < n_bytes;
+            const uint64_t m = __ballot(need);
+            if (m == 0ull) break;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if ((m >> (16 * r)) & 1ull) {      // wave-uniform
+                    if (row == r) {
+                        const uint32_t dst = (hi * 4u) & (kRingBytes - 1u);
+                        issue_block(dst);
+                        if (dst == 0u) issue_block(kRingBytes);   // ring head: mirror into the guard
+                    }
+                }
+            }
+            if (need) hi += kBlock;
+        }
+    };
+    // Soft symbols are written four at a time: lane t < 4 of a row keeps the value of the symbol with
+    // iter % 4 == t and stores it at the next refill point, right AFTER that point's s_waitcnt - a store
+    // per symbol would put a fresh store in front of every vmcnt(0) and make the wave wait out its latency.
+    double held = 0.0;
+    uint32_t held_off = 0;
+    bool held_valid = false;
+    auto flush_soft = [&]() {
+        if (held_valid) *(gdouble*)(soft_base + held_off) = held;
+        held_valid = false;
+    };
+    refill(!done, origin + (uint32_t)(int)mu, 16);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();                     // atan table visible (single wave: LDS ordering only)
+
+    for (uint32_t iter = 0;; ++iter) {
+        // ---- which demodulate() call comes next (ref :1026 / :1088 / :1173) ---------------------
+        if (!in_call && !done) {
+            const uint32_t remaining = n_avail - origin;
+            bool go = true;
+            last = false;
+            if (cfg.streaming) {
+                if (remaining >= OPV_CHUNK) N = OPV_CHUNK;
+                else if (eof && !tail_done && remaining > 0) { N = remaining; last = true; }
+                else { if (eof) tail_done = 1; go = false; }
+            } else {
+                if (!eof || tail_done) go = false;
+                else { N = n_avail; last = true; }
+            }
+            if (go && (overflow || (n_soft - soft_keep) + (uint64_t)(N / 38u + 2u) > cap_soft)) { overflow = 1; go = false; }
+            if (go) {
+                in_call = true;
+                first = true;
+                Nd = (double)N;
+                pos = mu;                                          // ref :217
+                soft_off0 = ((uint32_t)n_soft * 8u) & soft_bmask;
+                soft_off = soft_off0;
+            } else {
+                done = true;
+            }
+        }
+        if (__ballot(in_call) == 0ull) break;
+
+        if ((iter & 3u) == 0u) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): blocks and stores issued 4 symbols ago
+            flush_soft();
+            refill(in_call, origin + (uint32_t)(int)pos, 4);
+        }
+
+        if (in_call) {
+            if (pos + 40.0 + 10.0 < Nd) {                          // ref :221
+                // ---- taps (ref :122-128, :232-238) --------------------------------------------------
+                const double pf = pos + kf0;
+                const double fl = floor(pf);
+                const double f = pf - fl;
+                const int i0 = (int)fl;
+                const uint32_t byte0 = (((uint32_t)(i0 + (int)origin)) << 2) & (kRingBytes - 1u);
+                int w0[4], w1[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int* tap = reinterpret_cast<const int*>(ring + byte0 + 64u * (uint32_t)q);
+                    w0[q] = tap[0];
+                    w1[q] = tap[1];
+                }
+                if (first && pf < 0.0) {                           // early gate before the chunk: s[0] (ref :237)
+                    const int s0 = *reinterpret_cast<const int*>(ring + ((origin << 2) & (kRingBytes - 1u)));
+                    w0[0] = s0;
+                    w1[0] = s0;
+                }
+                // ---- LO: X[m] for m = t - 10 + 16 q ---------------------------------------------------
+                double xs[4], xc[4], s16, c16;
+                expj_small(kfs0 * fo, xs[0], xc[0]);
+                expj_small((16.0 * kDeltaPerHz) * fo, s16, c16);
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    xc[q] = fma(xc[q - 1], c16, -(xs[q - 1] * s16));
+                    xs[q] = fma(xc[q - 1], s16, xs[q - 1] * c16);
+                }
+                // X[40] = exp(j 40 d): uniform per row, needed by the NEXT symbol's phase detector
+                double x40s, x40c;
+                expj_small((40.0 * kDeltaPerHz) * fo, x40s, x40c);
+
+                double o1 = 0, o2 = 0, o3 = 0, o4 = 0;             // on-time P1..P4 partials
+                double eA = 0, eB = 0, eC = 0, eD = 0, lA = 0, lB = 0, lC = 0, lD = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int s0r = (int)(short)(w0[q] & 0xFFFF), s0i = w0[q] >> 16;    // ref :1023
+                    const int d_r = (int)(short)(w1[q] & 0xFFFF) - s0r, d_i = (w1[q] >> 16) - s0i;
+                    const double lr = fma(f, (double)d_r, (double)s0r);
+                    const double li = fma(f, (double)d_i, (double)s0i);
+                    const double zr = fma(lr, xc[q], li * xs[q]);   // Z = Lam conj(X)
+                    const double zi = fma(li, xc[q], -(lr * xs[q]));
+                    o1 = fma(zr, aO[q], o1); o2 = fma(zi, bO[q], o2); o3 = fma(zi, aO[q], o3); o4 = fma(zr, bO[q], o4);
+                    if (q < 3) { eA = fma(zr, aE[q], eA); eB = fma(zi, aE[q], eB); eC = fma(zi, bE[q], eC); eD = fma(zr, bE[q], eD); }
+                    if (q > 0) { lA = fma(zr, aL[q], lA); lB = fma(zi, aL[q], lB); lC = fma(zi, bL[q], lC); lD = fma(zr, bL[q], lD); }
+                }
+                // ---- on-time gate: soft value, dominant tone (ref :264-272) --------------------------
+                const double P1o = row_sum(o1), P2o = row_sum(o2), P3o = row_sum(o3), P4o = row_sum(o4);
+                const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;
+                const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;
+                const double en1 = fma(s1r_, s1r_, s1i_ * s1i_);
+                const double en2 = fma(s2r_, s2r_, s2i_ * s2i_);
+                const double soft = en2 - en1;                      // ref :268
+                const double nsg = mkd((dhi(soft) & (int)0x80000000) | 0x3ff00000, 0);  // -1 iff tone 1 dominates
+                const double sg = -nsg;
+                // ---- early / late gates of the dominant tone (ref :271-280) ---------------------------
+                const double Ere = row_sum(fma(sg, eC, eA)), Eim = row_sum(fma(-sg, eD, eB));
+                const double Lre = row_sum(fma(sg, lC, lA)), Lim = row_sum(fma(-sg, lD, lB));
+                const double ee = fma(Ere, Ere, Eim * Eim), el = fma(Lre, Lre, Lim * Lim);
+                const double num = el - ee, den = el + ee + 1e-10;
+                // ---- phase detector operands: dom * conj(prev) (ref :289-299, see k_frontend.hip) -----
+                const double dr = fma(sg, P2o, P1o), di = fma(-sg, P4o, P3o);
+                const double prs = fma(sg, pv.a, pv.b), pis = fma(sg, pv.c, -pv.d);
+                const double ar = fma(dr, prs, di * pis), ai = fma(di, prs, -(dr * pis));
+                const double cy = fma(ar, pv.x40c, ai * pv.x40s);   // Im z
+                const double cx = fma(ar, pv.x40s, -(ai * pv.x40c)); // Re z
+                const double ax = fabs(cx), ay = fabs(cy);
+                const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+                // ---- the two divides on one reciprocal ------------------------------------------------
+                const double dm = fmax(mx, 1e-100);
+                const double tt = den * dm;
+                double y = __builtin_amdgcn_rcp(tt);
+                y = fma(fma(-tt, y, 1.0), y, y);
+                y = fma(fma(-tt, y, 1.0), y, y);
+                const double iden = y * dm, idm = y * den;
+                double ratio = mn * idm;
+                ratio = fma(fma(-dm, ratio, mn), idm, ratio);
+                double ted = num * iden;
+                ted = fma(fma(-den, ted, num), iden, ted);
+                // ---- timing loop (ref :283-286, :313) ------------------------------------------------
+                tf = clampd(fma(0.00001, ted, tf), -0.1, 0.1);
+                const double adj = clampd(fma(0.005, ted, tf), -2.0, 2.0);
+                const double pos_next = pos + (40.0 + adj);
+                if ((uint32_t)t == (iter & 3u)) { held = soft; held_off = soft_off; held_valid = true; }
+                // ---- AFC (ref :289-306): not on the first symbol of a call -------------------------------
+                if (!first) {
+                    const double kd = rint(ratio * 32.0);
+                    const int k = (int)kd;
+                    const double h = fma(kd, -1.0 / 32.0, ratio);
+                    const double* trow = atab + k * (int)kTabRow;
+                    double pd = fma(trow[8], h, trow[7]);
+                    pd = fma(pd, h, trow[6]);
+                    pd = fma(pd, h, trow[5]);
+                    pd = fma(pd, h, trow[4]);
+                    pd = fma(pd, h, trow[3]);
+                    pd = fma(pd, h, trow[2]);
+                    pd = fma(pd, h, trow[1]);
+                    pd = fma(pd, h, trow[0]);
+                    pd = (ay > ax) ? 1.57079632679489661923 - pd : pd;
+                    const double sx = mkd((dhi(cx) & (int)0x80000000) | 0x3ff00000, 0);
+                    pd = fma(sx, pd, fma(-sx, 1.57079632679489661923, 1.57079632679489661923));
+                    pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));
+                    if (mx == 0.0)                                   // digital silence on either side
+                        pd = silence_pd_x4(dr, di, pv.a, pv.b, pv.c, pv.d, pv.x40c, pv.x40s, soft < 0.0, fo_sum,
+                                           (uint32_t)n_soft + (((soft_off - soft_off0) & soft_bmask) >> 3));
+                    const double fo_used = fo;
+                    fo = clampd(fma(kgain, pd, fo), -2000.0, 2000.0);
+                    fo_sum += fo_used;
+                } else {
+                    fo_sum += fo;
+                }
+                soft_off = (soft_off + 8u) & soft_bmask;
+                pv.a = P1o; pv.b = P2o; pv.c = P3o; pv.d = P4o; pv.x40c = x40c; pv.x40s = x40s;
+                pos = pos_next;
+                first = false;
+            } else {
+                // ---- end of this demodulate() call (ref :318-328, :1067-1076) ---------------------
+                const uint32_t nsym_call = ((soft_off - soft_off0) & soft_bmask) >> 3;
+                const uint32_t used = (uint32_t)pos;
+                mu = pos - (double)used;
+                const uint32_t leftover = N - used;
+                if (t == 0) {
+                    double* c = chunk_log + 5 * (size_t)(n_chunks % cap_chunks);
+                    c[0] = fo; c[1] = tf; c[2] = mu; c[3] = (double)leftover; c[4] = (double)nsym_call;
+                }
+                ++n_chunks;
+                n_soft += nsym_call;
+                total_samples += N;
+                origin += (leftover > 0u && leftover < N) ? used : N;
+                in_call = false;
+                if (last) { tail_done = 1; done = true; }
+            }
+        }
+    }
+
+    flush_soft();
+    if (have && t == 0) {
+        st.freq_offset = fo; st.timing_freq = tf; st.mu = mu;
+        st.p1r = pv.a; st.p1i = pv.b; st.p2r = pv.c; st.p2i = pv.d; st.x40c = pv.x40c; st.x40s = pv.x40s;
+        st.fo_sum = fo_sum;
+        st.origin = origin; st.n_soft = n_soft; st.total_samples = total_samples;
+        st.n_chunks = n_chunks; st.tail_done = tail_done; st.overflow = overflow;
+    }
+}

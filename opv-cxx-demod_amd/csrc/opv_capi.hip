@@ -19,6 +19,7 @@
 
 extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg);
 extern "C" __global__ void k_msk_frontend(OpvStream*, OpvGlobalCfg);
+extern "C" __global__ void k_msk_frontend_x4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_sync_track(OpvStream*);
 extern "C" __global__ void k_frame_decode(OpvStream*);
 extern "C" __global__ void k_decode_payloads(const double*, uint32_t, uint8_t*, int32_t*, int8_t*, int8_t*, uint8_t*);
@@ -42,6 +43,8 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
         hipError_t _e = (expr);                                   \
         if (_e != hipSuccess) return fail(OPV_EHIP, #expr, _e);   \
     } while (0)
+
+constexpr int kFrontendX4MinStreams = 8192;  // measured cross-over on MI355X (67 vs 56 GS/s there)
 
 struct StreamIn {  // host -> device per-round update
     const int16_t* iq;
@@ -123,6 +126,7 @@ struct opv_ctx {
     double tx_ph1 = 0.0, tx_ph2 = 0.0;   // phases after the last cached symbol
     double* d_tx_phases = nullptr;
     size_t d_tx_phases_cap = 0;          // symbols
+    int frontend = 0;  // 0: by stream count, 1: one wave per stream, 4: four streams per wave (opv_set_frontend)
     bool timing = false;
     bool timing_valid = false;
     hipEvent_t ev[8] = {};
@@ -362,7 +366,12 @@ extern "C" int opv_process(opv_ctx* c) {
     if (tm) HIPCHK(hipEventRecord(c->ev[0], c->stream));
     k_offset_search<<<S, 256, 0, c->stream>>>(c->d_streams, g);
     if (tm) { HIPCHK(hipEventRecord(c->ev[1], c->stream)); HIPCHK(hipEventRecord(c->ev[2], c->stream)); }
-    k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g);
+    // one wave per stream has the shortest per-symbol latency (what counts while SIMDs are idle, and up to
+    // two waves per SIMD); four streams per wave issue 137 instead of 213 instructions per symbol and
+    // stream, which only pays once there are more streams than the chip has wave slots for
+    const bool x4 = c->frontend == 4 || (c->frontend == 0 && S >= kFrontendX4MinStreams);
+    if (x4) k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
+    else k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g);
     if (tm) { HIPCHK(hipEventRecord(c->ev[3], c->stream)); HIPCHK(hipEventRecord(c->ev[4], c->stream)); }
     k_sync_track<<<S, 64, 0, c->stream>>>(c->d_streams);
     if (tm) { HIPCHK(hipEventRecord(c->ev[5], c->stream)); HIPCHK(hipEventRecord(c->ev[6], c->stream)); }
@@ -373,6 +382,14 @@ extern "C" int opv_process(opv_ctx* c) {
     if (tm) { HIPCHK(hipEventRecord(c->ev[7], c->stream)); c->timing_valid = true; }
     k_collect_counts<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_counts, S);
     HIPCHK(hipGetLastError());
+    return OPV_OK;
+}
+
+extern "C" int opv_set_frontend(opv_ctx* c, int streams_per_wave) {
+    if (!c) return fail(OPV_EINVAL, "null context");
+    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4)
+        return fail(OPV_EINVAL, "opv_set_frontend: 0 (automatic), 1 or 4 streams per wave");
+    c->frontend = streams_per_wave;
     return OPV_OK;
 }
 

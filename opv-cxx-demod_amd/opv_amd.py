@@ -10,6 +10,7 @@ or use ``load_opv_amd()`` from the repo-root ``__graft_entry__``.
 There is no CPU fallback: if the library is missing or no MI355X is visible, calls raise.
 """
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -28,7 +29,7 @@ SAMPLE_RATE = 2168000.0
 
 EXPORTS = [
     "opv_create", "opv_destroy", "opv_last_error", "opv_abi_version", "opv_push_iq", "opv_flush",
-    "opv_attach_device_iq", "opv_process", "opv_sync", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
+    "opv_attach_device_iq", "opv_process", "opv_sync", "opv_set_frontend", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_tap_soft", "opv_tap_chunks",
     "opv_tap_offset_energies", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_modulated_samples",
     "opv_tx_modulate", "opv_channel_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device",
@@ -97,6 +98,7 @@ def lib():
         L.opv_attach_device_iq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
         L.opv_process.argtypes = [C.c_void_p]
         L.opv_sync.argtypes = [C.c_void_p]
+        L.opv_set_frontend.argtypes = [C.c_void_p, C.c_int]
         L.opv_reset_stream.argtypes = [C.c_void_p, C.c_int]
         L.opv_pop_frames.restype = C.c_long
         L.opv_pop_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -165,6 +167,8 @@ class Demod:
                        device, 1, int(max_samples))
         self.h = C.c_void_p()
         _chk(lib().opv_create(C.byref(self.h), n_streams, C.byref(self.cfg)))
+        if os.environ.get("OPV_FRONTEND"):      # dev switch: run everything on one mapping (0 / 1 / 4)
+            self.set_frontend(int(os.environ["OPV_FRONTEND"]))
 
     def close(self):
         if getattr(self, "h", None):
@@ -192,6 +196,9 @@ class Demod:
 
     def sync(self):
         _chk(lib().opv_sync(self.h))
+
+    def set_frontend(self, streams_per_wave):
+        _chk(lib().opv_set_frontend(self.h, int(streams_per_wave)))
 
     def reset(self, stream=-1):
         _chk(lib().opv_reset_stream(self.h, stream))

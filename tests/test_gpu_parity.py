@@ -702,3 +702,68 @@ def test_clock_rate_error_and_random_channels_fuzz(amd, oracle, iq10, iq100):
         d.close()
         if streaming:
             assert len(kinds) >= 8, kinds        # the clock error really moved the chunk grid (leftovers 18..50)
+
+
+def test_four_streams_per_wave_mapping(amd, oracle, iq10, iq100):
+    """k_msk_frontend_x4 (four streams per wavefront, the mapping the shim picks from 8192 streams) on
+    the cases that exercise its per-row machinery: rows with different chunk schedules (clock error,
+    truncation), an idle row (stream count not a multiple of 4), the first-symbol early-gate clamp,
+    the end-of-capture partial block, digital-silence gaps, batch mode, incremental pushes."""
+    rng = np.random.default_rng(4)
+    caps = [iq10, iq10[: 2 * 91022], iq100[: 2 * 86720 * 12]]
+    for k in range(10):
+        ppm = float(rng.choice([-300.0, -40.0, 0.0, 25.0, 180.0]))
+        x = resample_clock(iq10, ppm) if ppm else iq10
+        x = impair(x, amp=float(rng.uniform(400, 8000)), f0_hz=float(rng.uniform(-2100, 2100)),
+                   ebn0_db=float(rng.uniform(9, 22)), seed=300 + k)
+        caps.append(x[: 2 * int(rng.integers(x.size // 4, x.size // 2))] if k % 3 == 0 else x)
+    gapped, _ = _gapped_capture(oracle, iq10)
+    assert len(caps) % 4 == 1
+    nmax = max(c.size // 2 for c in caps + [gapped])
+    for streaming in (True, False):
+        d = amd.Demod(len(caps), max_samples=nmax + 64, streaming=streaming)
+        d.set_frontend(4)
+        got = d.receive(caps)
+        for k, x in enumerate(caps):
+            check_stream(amd, got[k], oracle.receive(x, streaming=streaming), f"x4 stream {k} streaming={streaming}")
+        d.close()
+    # silence gaps (signed-zero rule of the phase detector), streaming
+    exp = oracle.receive(gapped, streaming=True)
+    d = amd.Demod(2, max_samples=nmax + 64, streaming=True)
+    d.set_frontend(4)
+    g = d.receive([gapped, iq10])
+    d.close()
+    assert g[0]["state"].total_symbols == exp["n_soft"]
+    scale = np.mean(np.abs(exp["soft"]))
+    assert np.max(np.abs(g[0]["soft"] - exp["soft"])) / scale < 1e-8
+    assert np.allclose(g[0]["chunks"], exp["chunks"], rtol=0, atol=1e-7)
+    # every tail length mod 4 and mod 40 (partial 16-byte piece at the end of the capture)
+    lens = list(range(91003, 91048))
+    d = amd.Demod(len(lens), max_samples=100000, streaming=True)
+    d.set_frontend(4)
+    got = d.receive([iq10[: 2 * n] for n in lens])
+    d.close()
+    for n, g1 in zip(lens, got):
+        e = oracle.receive(iq10[: 2 * n], streaming=True)
+        assert g1["state"].total_symbols == e["n_soft"], n
+        a, _ = soft_err(g1["soft"], e["soft"])
+        assert a < SOFT_TIGHT and np.allclose(g1["chunks"], e["chunks"], rtol=0, atol=1e-9), (n, a)
+    # incremental pushes (opv-modem's 16 KB reads) through the x4 mapping, 5 streams
+    d = amd.Demod(5, max_samples=iq10.size // 2 + 64, streaming=True)
+    d.set_frontend(4)
+    step = 4096
+    for a0 in range(0, iq10.size // 2, step):
+        for s in range(5):
+            d.push(s, iq10[2 * a0: 2 * min(a0 + step, iq10.size // 2)])
+        if (a0 // step) % 7 == 0:
+            d.process()
+    for s in range(5):
+        d.flush(s)
+    d.process(); d.sync()
+    exp = oracle.receive(iq10, streaming=True)
+    for s in range(5):
+        fr, meta = d.pop_frames(s)
+        assert np.array_equal(fr, exp["frames"]) and np.array_equal(meta["release_symbol"], exp["frame_sym"])
+        a, _ = soft_err(d.soft(s), exp["soft"])
+        assert a < SOFT_TIGHT
+    d.close()
