@@ -339,6 +339,25 @@ def main():
             res["config"] = f"{S} streams x {FH} frames, rounds of {RH} frames, pinned host buffers"
             extras["pcie_inclusive"] = res
             hp.close()
+            # live serving round: one 86720-sample chunk (40 ms of signal) per stream pushed from host memory,
+            # processed, frames popped - what a multi-stream receiver does every 40 ms
+            lv = amd.Demod(S, max_samples=4 * FRAME_SAMPLES + 65536, streaming=True, device=local_rank)
+            rounds = []
+            for r in range(min(14, FH - 1)):
+                blks = [host_np[k][2 * r * FRAME_SAMPLES: 2 * (r + 1) * FRAME_SAMPLES] for k in range(S)]
+                t0 = time.perf_counter()
+                lv.push_batch(range(S), blks)
+                t1 = time.perf_counter()
+                lv.process()
+                lv.sync()
+                t2 = time.perf_counter()
+                got = sum(len(lv.pop_frames(k)[0]) for k in range(S))
+                t3 = time.perf_counter()
+                rounds.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2, got))
+            med = lambda i: round(1e3 * float(np.median([x[i] for x in rounds[3:]])), 3)
+            extras["live_round"] = {"streams": S, "signal_ms_per_round": 40.0, "round_ms": med(0), "push_ms": med(1),
+                                    "process_ms": med(2), "pop_ms": med(3), "frames_per_round": int(rounds[-1][4])}
+            lv.close()
             del host, host_np
         out["extras"] = extras
         base = d_base.cpu().numpy()

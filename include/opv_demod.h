@@ -115,6 +115,11 @@ int opv_abi_version(void);
  * :1132-1135 batch): host-endian interleaved int16 I,Q. The caller keeps ownership; the
  * samples are copied to the stream's device buffer. Nothing is computed until opv_process. */
 int opv_push_iq(opv_ctx* ctx, int stream, const int16_t* iq_interleaved, size_t n_samples);
+/* The same for several streams of a multi-stream server in one call (what N copies of the reader loop
+ * :1021-1026 do in N reference processes): all copies are enqueued, then awaited once. Stops at the first
+ * error; streams before it have been pushed. */
+int opv_push_iq_batch(opv_ctx* ctx, int count, const int* streams, const int16_t* const* iq_interleaved,
+                      const size_t* n_samples);
 /* EOF on a stream: enables the tail processing of :1088-1113 (streaming) or the single
  * whole-capture demodulate of :1166-1173 (batch) at the next opv_process. */
 int opv_flush(opv_ctx* ctx, int stream);

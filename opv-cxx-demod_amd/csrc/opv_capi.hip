@@ -131,12 +131,56 @@ struct opv_ctx {
     bool timing_valid = false;
     hipEvent_t ev[8] = {};
 
+    // Host copies of the record pools (frames, metrics, frame records, events), fetched once per round
+    // with four copies for ALL streams instead of three or four small copies per stream and pop: a
+    // server popping 256 live streams spent 10 ms per 40 ms round in those copies. Pools above
+    // kPoolMirrorMax (big offline captures) are read per stream as before.
+    static constexpr size_t kPoolMirrorMax = 64u << 20;
+    std::vector<uint8_t> m_frames;
+    std::vector<int32_t> m_metrics;
+    std::vector<OpvFrameRec> m_frec;
+    std::vector<OpvEventRec> m_events;
+    unsigned mirror_epoch = 0, pools_epoch = ~0u;
+
     int refresh() {
         if (mirror_valid) return OPV_OK;
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipMemcpy(mirror.data(), d_streams, sizeof(OpvStream) * n_streams, hipMemcpyDeviceToHost));
         mirror_valid = true;
+        ++mirror_epoch;
         return OPV_OK;
+    }
+    size_t pool_bytes() const {
+        const size_t S = (size_t)n_streams;
+        return S * ((size_t)cap_frames * (OPV_FB + sizeof(int32_t) + sizeof(OpvFrameRec)) + (size_t)cap_events * sizeof(OpvEventRec));
+    }
+    // after refresh(): bring the pools over if they are small enough; returns whether host views exist
+    int ensure_pools(bool* have) {
+        *have = false;
+        if (pool_bytes() > kPoolMirrorMax) return OPV_OK;
+        if (pools_epoch != mirror_epoch) {
+            const size_t S = (size_t)n_streams;
+            m_frames.resize((size_t)OPV_FB * cap_frames * S);
+            m_metrics.resize((size_t)cap_frames * S);
+            m_frec.resize((size_t)cap_frames * S);
+            m_events.resize((size_t)cap_events * S);
+            HIPCHK(hipMemcpy(m_frames.data(), d_frames, m_frames.size(), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(m_metrics.data(), d_metrics, m_metrics.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(m_frec.data(), d_frec, m_frec.size() * sizeof(OpvFrameRec), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(m_events.data(), d_events, m_events.size() * sizeof(OpvEventRec), hipMemcpyDeviceToHost));
+            pools_epoch = mirror_epoch;
+        }
+        *have = true;
+        return OPV_OK;
+    }
+    // host address of a device pointer into one of the mirrored pools (nullptr if it is not one)
+    const void* host_view(const void* d) const {
+        auto in = [&](const void* base, size_t bytes) { return (const char*)d >= (const char*)base && (const char*)d < (const char*)base + bytes; };
+        if (in(d_frames, m_frames.size())) return m_frames.data() + ((const char*)d - (const char*)d_frames);
+        if (in(d_metrics, m_metrics.size() * sizeof(int32_t))) return (const char*)m_metrics.data() + ((const char*)d - (const char*)d_metrics);
+        if (in(d_frec, m_frec.size() * sizeof(OpvFrameRec))) return (const char*)m_frec.data() + ((const char*)d - (const char*)d_frec);
+        if (in(d_events, m_events.size() * sizeof(OpvEventRec))) return (const char*)m_events.data() + ((const char*)d - (const char*)d_events);
+        return nullptr;
     }
 };
 
@@ -283,15 +327,15 @@ static int compact_stream(opv_ctx* c, int s) {
     return OPV_OK;
 }
 
-extern "C" int opv_push_iq(opv_ctx* c, int s, const int16_t* iq, size_t n) {
+static int push_enqueue(opv_ctx* c, int s, const int16_t* iq, size_t n) {
     if (int r = check_stream(c, s)) return r;
     HostStream& h = c->hs[s];
     if (h.attached) return fail(OPV_ESTATE, "stream has an attached device capture");
     if (h.eof) return fail(OPV_ESTATE, "push after flush");
     if (n == 0) return OPV_OK;
     if (!iq) return fail(OPV_EINVAL, "null IQ pointer");
-    HIPCHK(hipSetDevice(c->cfg.device));
     if (h.n_avail + n > c->cfg.max_samples) {
+        HIPCHK(hipStreamSynchronize(c->copy_stream));  // copies enqueued earlier in this batch land first
         if (int r = compact_stream(c, s)) return r;
         if (h.n_avail + n > c->cfg.max_samples)
             return fail(OPV_ECAPACITY, "opv_cfg.max_samples exceeded (unprocessed samples + this push do not fit; "
@@ -304,13 +348,31 @@ extern "C" int opv_push_iq(opv_ctx* c, int s, const int16_t* iq, size_t n) {
     }
     // On the copy stream: the kernels of an opv_process still in flight only read samples below the
     // n_avail they were launched with, so new samples land behind them while they run (H2D over
-    // PCIe overlaps compute). The caller keeps ownership of `iq`: the copy must have left the host
-    // buffer before we return, which is a wait for THIS copy only, not for the kernels.
+    // PCIe overlaps compute).
     HIPCHK(hipMemcpyAsync(h.d_iq_owned + 2 * h.n_avail, iq, n * 4, hipMemcpyHostToDevice, c->copy_stream));
-    HIPCHK(hipStreamSynchronize(c->copy_stream));
     h.n_avail += n;
     h.dirty = true;
     return OPV_OK;
+}
+
+extern "C" int opv_push_iq(opv_ctx* c, int s, const int16_t* iq, size_t n) {
+    if (!c) return fail(OPV_EINVAL, "null context");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    if (int r = push_enqueue(c, s, iq, n)) return r;
+    // The caller keeps ownership of `iq`: the copy must have left the host buffer before we return,
+    // which is a wait for THIS copy only, not for the kernels.
+    HIPCHK(hipStreamSynchronize(c->copy_stream));
+    return OPV_OK;
+}
+
+extern "C" int opv_push_iq_batch(opv_ctx* c, int count, const int* streams, const int16_t* const* iq, const size_t* n_samples) {
+    if (!c) return fail(OPV_EINVAL, "null context");
+    if (count < 0 || (count > 0 && (!streams || !iq || !n_samples))) return fail(OPV_EINVAL, "opv_push_iq_batch: bad arguments");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    int rc = OPV_OK;
+    for (int i = 0; i < count && rc == OPV_OK; ++i) rc = push_enqueue(c, streams[i], iq[i], n_samples[i]);
+    HIPCHK(hipStreamSynchronize(c->copy_stream));  // one wait for all copies; the buffers are the caller's again
+    return rc;
 }
 
 extern "C" int opv_flush(opv_ctx* c, int s) {
@@ -442,9 +504,18 @@ extern "C" int opv_kernel_times(opv_ctx* c, float ms[4]) {
 }
 
 // copies records [first, first+n) of a device ring with `cap` slots of `elem` bytes into dst (host)
-static int ring_to_host(void* dst, const void* d_ring, uint32_t first, uint32_t n, uint32_t cap, size_t elem) {
+static int ring_to_host(opv_ctx* c, void* dst, const void* d_ring, uint32_t first, uint32_t n, uint32_t cap, size_t elem) {
     const uint32_t p0 = first % cap;
     const uint32_t run = n < cap - p0 ? n : cap - p0;
+    bool have = false;
+    if (int r = c->ensure_pools(&have)) return r;
+    if (have) {
+        if (const void* h_ring = c->host_view(d_ring)) {
+            std::memcpy(dst, (const char*)h_ring + (size_t)p0 * elem, (size_t)run * elem);
+            if (run < n) std::memcpy((char*)dst + (size_t)run * elem, h_ring, (size_t)(n - run) * elem);
+            return OPV_OK;
+        }
+    }
     HIPCHK(hipMemcpy(dst, (const char*)d_ring + (size_t)p0 * elem, (size_t)run * elem, hipMemcpyDeviceToHost));
     if (run < n) HIPCHK(hipMemcpy((char*)dst + (size_t)run * elem, d_ring, (size_t)(n - run) * elem, hipMemcpyDeviceToHost));
     return OPV_OK;
@@ -472,9 +543,9 @@ extern "C" long opv_pop_frames(opv_ctx* c, int s, uint8_t* out, size_t cap, opv_
         met.resize(n);
         rec.resize(n);
         fr.resize((size_t)n * OPV_FB);
-        if (int r = ring_to_host(met.data(), st.metrics, f, n, st.cap_frames, sizeof(int32_t))) return r;
-        if (int r = ring_to_host(rec.data(), st.frec, f, n, st.cap_frames, sizeof(OpvFrameRec))) return r;
-        if (int r = ring_to_host(fr.data(), st.frames, f, n, st.cap_frames, OPV_FB)) return r;
+        if (int r = ring_to_host(c, met.data(), st.metrics, f, n, st.cap_frames, sizeof(int32_t))) return r;
+        if (int r = ring_to_host(c, rec.data(), st.frec, f, n, st.cap_frames, sizeof(OpvFrameRec))) return r;
+        if (int r = ring_to_host(c, fr.data(), st.frames, f, n, st.cap_frames, OPV_FB)) return r;
         bool stop = false;
         for (uint32_t k = 0; k < n; ++k, ++f) {
             if (met[k] == INT32_MIN) { stop = true; break; }  // released but not decoded yet (cannot happen after opv_process)
@@ -507,7 +578,7 @@ extern "C" long opv_pop_events(opv_ctx* c, int s, opv_event* out, size_t cap) {
     uint32_t n = ne - h.events_popped;
     if (n > cap) n = (uint32_t)cap;
     static_assert(sizeof(opv_event) == sizeof(OpvEventRec), "event layouts must match");
-    if (int r = ring_to_host(out, st.events, h.events_popped, n, st.cap_events, sizeof(OpvEventRec))) return r;
+    if (int r = ring_to_host(c, out, st.events, h.events_popped, n, st.cap_events, sizeof(OpvEventRec))) return r;
     h.events_popped += n;
     return (long)n;
 }
@@ -536,7 +607,7 @@ extern "C" int opv_get_state(opv_ctx* c, int s, opv_stream_state* out) {
         uint32_t n = st.n_frames - h.popped;
         if (n > st.cap_frames) n = st.cap_frames;
         std::vector<int32_t> met(n);
-        if (int r = ring_to_host(met.data(), st.metrics, h.popped, n, st.cap_frames, sizeof(int32_t))) return r;
+        if (int r = ring_to_host(c, met.data(), st.metrics, h.popped, n, st.cap_frames, sizeof(int32_t))) return r;
         for (int32_t m : met)
             if (m >= 0) { out->frames_decoded++; if (m == 0) out->frames_perfect++; }
     }

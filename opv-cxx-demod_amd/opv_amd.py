@@ -28,7 +28,7 @@ CHUNK_SAMPLES = 86720
 SAMPLE_RATE = 2168000.0
 
 EXPORTS = [
-    "opv_create", "opv_destroy", "opv_last_error", "opv_abi_version", "opv_push_iq", "opv_flush",
+    "opv_create", "opv_destroy", "opv_last_error", "opv_abi_version", "opv_push_iq", "opv_push_iq_batch", "opv_flush",
     "opv_attach_device_iq", "opv_process", "opv_sync", "opv_set_frontend", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_tap_soft", "opv_tap_chunks",
     "opv_tap_offset_energies", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_modulated_samples",
@@ -95,6 +95,7 @@ def lib():
         L.opv_destroy.restype = None
         L.opv_push_iq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.opv_flush.argtypes = [C.c_void_p, C.c_int]
+        L.opv_push_iq_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.opv_attach_device_iq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
         L.opv_process.argtypes = [C.c_void_p]
         L.opv_sync.argtypes = [C.c_void_p]
@@ -184,6 +185,15 @@ class Demod:
     def push(self, stream, iq):
         iq = np.ascontiguousarray(iq, np.int16).reshape(-1)
         _chk(lib().opv_push_iq(self.h, stream, iq.ctypes.data, iq.size // 2))
+
+    def push_batch(self, streams, blocks):
+        """opv_push_iq_batch: blocks[i] (int16 IQ) goes to streams[i]; one wait for all copies."""
+        blocks = [np.ascontiguousarray(b, np.int16).reshape(-1) for b in blocks]
+        n = len(blocks)
+        ids = (C.c_int * n)(*[int(s) for s in streams])
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in blocks])
+        lens = (C.c_size_t * n)(*[b.size // 2 for b in blocks])
+        _chk(lib().opv_push_iq_batch(self.h, n, ids, ptrs, lens))
 
     def flush(self, stream):
         _chk(lib().opv_flush(self.h, stream))

@@ -767,3 +767,45 @@ def test_four_streams_per_wave_mapping(amd, oracle, iq10, iq100):
         a, _ = soft_err(d.soft(s), exp["soft"])
         assert a < SOFT_TIGHT
     d.close()
+
+
+def test_push_batch_and_pooled_pops(amd, oracle, iq10):
+    """A multi-stream server's round: opv_push_iq_batch (all copies enqueued, one wait) + pops served from
+    the once-per-round host copy of the record pools; 12 streams, ragged block sizes, a pop every round."""
+    caps = [impair(iq10, amp=2500.0, f0_hz=-1800.0 + 300.0 * k, ebn0_db=15.0, seed=40 + k) for k in range(11)] + [iq10]
+    S = len(caps)
+    d = amd.Demod(S, max_samples=iq10.size // 2 + 64, streaming=True)
+    sizes = [30011, 86720, 4096, 123457]
+    at = [0] * S
+    frames = [[] for _ in range(S)]
+    events = [[] for _ in range(S)]
+    r = 0
+    while any(a < c.size // 2 for a, c in zip(at, caps)):
+        ids, blks = [], []
+        for k in range(S):
+            n = min(sizes[(r + k) % 4], caps[k].size // 2 - at[k])
+            if n > 0:
+                ids.append(k); blks.append(caps[k][2 * at[k]: 2 * (at[k] + n)]); at[k] += n
+        d.push_batch(ids, blks)
+        d.process()
+        for k in range(S):
+            fr, meta = d.pop_frames(k)
+            frames[k].append((fr, meta))
+            events[k].append(d.pop_events(k))
+        r += 1
+    for k in range(S):
+        d.flush(k)
+    d.process()
+    for k in range(S):
+        fr, meta = d.pop_frames(k)
+        frames[k].append((fr, meta))
+        events[k].append(d.pop_events(k))
+        exp = oracle.receive(caps[k], streaming=True)
+        got_fr = np.concatenate([f for f, _ in frames[k]])
+        got_meta = np.concatenate([m for _, m in frames[k]])
+        assert np.array_equal(got_fr, exp["frames"]), k
+        assert np.array_equal(got_meta["viterbi_metric"], exp["metrics"]) and np.array_equal(got_meta["release_symbol"], exp["frame_sym"]), k
+        events_match(amd, np.concatenate(events[k]), exp["events"])
+        a, _ = soft_err(d.soft(k), exp["soft"])
+        assert a < SOFT_TIGHT, (k, a)
+    d.close()
