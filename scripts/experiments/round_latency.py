@@ -26,4 +26,6 @@ for r in range(R):
     t3 = time.perf_counter()
     lat.append(t3 - t0); t_push.append(t1 - t0); t_proc.append(t2 - t1); t_pop.append(t3 - t2)
 m = lambda a: 1e3 * float(np.median(a[3:]))
+mean = lambda a: 1e3 * float(np.mean(a[3:]))
+print(f"S={S}: mean round {mean(lat):.3f} ms (push {mean(t_push):.3f}, process {mean(t_proc):.3f}, pop {mean(t_pop):.3f}); max round {1e3*max(lat[3:]):.3f}")
 print(f"S={S}: round {m(lat):.3f} ms = push {m(t_push):.3f} + process+sync {m(t_proc):.3f} + pop {m(t_pop):.3f}; frames {nfr}; chunk = 40 ms of signal per stream")
