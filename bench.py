@@ -79,7 +79,7 @@ def cpu_all_cores(iq_bytes, n_samples):
     ref = ROOT / "oracle" / "_ref" / "opv-demod"
     if not ref.exists():
         return None
-    cores = len(os.sched_getaffinity(0))
+    cores = min(len(os.sched_getaffinity(0)), 16)     # a one-GPU job's CPU share on the pool's boxes is 16 cores
     nfr = min(200, n_samples // FRAME_SAMPLES)
     part = iq_bytes[: nfr * FRAME_SAMPLES * 4]
     t0 = time.perf_counter()
