@@ -308,6 +308,7 @@ def main():
                 continue
             sub_n = nfr * FRAME_SAMPLES
             m = amd.Demod(ns, max_samples=sub_n + 64, streaming=True, device=local_rank)
+            m.enable_timing(True)
             ent = {}
             for spw in (1, 4):                          # streams per wavefront (opv_set_frontend)
                 if spw == 4 and ns < 8192:         # the four-per-wave mapping only pays from ~8k streams
@@ -325,7 +326,9 @@ def main():
                     t1 = time.perf_counter() - t0
                 f_, m_, c_, cap_ = m.device_frames()
                 cnt = torch.as_tensor(DevPtr(c_, (ns,), "<i4"), device=dev).cpu().numpy()
+                fe_ms = m.kernel_times()["msk_frontend"]
                 ent[f"{spw}_per_wave"] = {"Msamples/s": round(ns * sub_n / t1 / 1e6, 1), "ms": round(t1 * 1e3, 2),
+                                          "frontend_alone_Msamples/s": round(ns * sub_n / fe_ms / 1e3, 1),
                                           "frames_released": int(cnt.sum())}
             sweep[f"{ns}x{nfr}"] = ent
             m.close()

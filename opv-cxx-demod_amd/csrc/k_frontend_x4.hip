@@ -11,9 +11,9 @@
 // swaps, no v_readlane), and the per-sample work grows only from one to four taps per lane.
 // Measured (rocprofv3 PMC, MI355X): 448 VALU + 87 SALU + 12 LDS/VMEM per wave and symbol = 137 issued
 // instructions per symbol and stream instead of 213. Because a wave now carries four streams, the chip
-// fills four times later: the mapping only overtakes one-wave-per-stream at ~8192 streams per GPU
-// (67 vs 56 GS/s); below that the one-wave kernel, with its shorter per-symbol latency, is the default
-// (DESIGN.md §3.1).
+// fills four times later: the mapping overtakes one-wave-per-stream at ~8192 streams per GPU (front-end
+// alone 173 vs 112 GS/s; one wave per stream is VALU-issue-bound at 112-115 GS/s from 2048 streams on);
+// below that the one-wave kernel, with its shorter per-symbol latency, is the default.
 //
 // Mapping (row r = lane / 16 serves stream 4*blockIdx.x + r, t = lane % 16):
 //   * lane t owns the interpolated samples Lam_j = L(pos + j - 10), j = t + 16 q, q = 0..3 (j < 60); the

@@ -44,7 +44,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
         if (_e != hipSuccess) return fail(OPV_EHIP, #expr, _e);   \
     } while (0)
 
-constexpr int kFrontendX4MinStreams = 8192;  // measured cross-over on MI355X (67 vs 56 GS/s there)
+constexpr int kFrontendX4MinStreams = 8192;  // measured cross-over on MI355X (front-end alone 173 vs 112 GS/s there, 87 vs 109 at 4096)
 
 struct StreamIn {  // host -> device per-round update
     const int16_t* iq;

@@ -12,6 +12,7 @@ n = iq.size // 2
 d_iq = torch.from_numpy(iq).cuda()
 d = amd.Demod(S, max_samples=n + 64, streaming=True)
 d.set_frontend(spw)
+d.enable_timing(True)
 for rep in range(2):
     d.reset()
     for s in range(S):
@@ -21,4 +22,6 @@ for rep in range(2):
     d.process(); d.sync()
     dt = time.perf_counter() - t0
 fr, _ = d.pop_frames(S - 1)
-print(f"S={S} F={F} spw={spw}: {S * n / dt / 1e6:.1f} Msamples/s, {dt * 1e3:.2f} ms, frames {len(fr)}, symbols/stream {n // 40}")
+kt = d.kernel_times()
+fe = S * n / (kt["msk_frontend"] * 1e-3) / 1e6
+print(f"S={S} F={F} spw={spw}: front-end alone {fe:.1f} Msamples/s ({kt['msk_frontend']:.2f} ms), whole process {S * n / dt / 1e6:.1f} Msamples/s ({dt * 1e3:.2f} ms), kernels {kt}, frames {len(fr)}")
