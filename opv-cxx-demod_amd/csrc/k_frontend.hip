@@ -127,6 +127,11 @@ __device__ inline double clampd(double v, double lo, double hi) { return fmin(fm
 // q, r near-minimax of degree 4 on u <= 0.0823 (mpmath chebyfit; abs error 1e-19 / 1.3e-18).
 // One asm block: the constants stay in registers as written and hipcc's hazard recogniser does
 // not pad between the dependent FMAs.
+// instantiations of the per-symbol body (see `symbol` in the kernel)
+struct TagFirst { static constexpr bool first = true, wide = true; };     // first symbol of a demodulate() call
+struct TagSecond { static constexpr bool first = false, wide = true; };   // second symbol under an out-of-range -o
+struct TagSteady { static constexpr bool first = false, wide = false; };  // everything else
+
 struct PrevSums {
     double a, b, c, d;  // on-time P1..P4
     double x40c, x40s;  // X[40] = exp(j 40 d) of that symbol
@@ -385,15 +390,24 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
         //      arithmetic -> 32 B through LDS, the round trip under the rest of that arithmetic
         //   3. one reciprocal for both divides -> atan table row requested -> timing loop, soft
         //      store, tap address under that LDS latency -> taps requested -> atan polynomial
-        auto symbol = [&](auto first_tag, PrevSums& cur, const PrevSums& prv) {
-            constexpr bool kFirst = decltype(first_tag)::value;
+        auto symbol = [&](auto tag, PrevSums& cur, const PrevSums& prv) {
+            constexpr bool kFirst = decltype(tag)::first;   // first symbol of a call: no AFC update (ref :289)
+            constexpr bool kWide = decltype(tag)::wide;     // fo may still be an unclamped -o value
             // ---- the lane's sample and LO factor ----------------------------------------------------
             const int s0r = (int)(short)(w0 & 0xFFFF), s0i = w0 >> 16;      // ref :1023
             const int d_r = (int)(short)(w1 & 0xFFFF) - s0r, d_i = (w1 >> 16) - s0i;
             const double lr = fma(f, (double)d_r, (double)s0r);              // ref :122-128
             const double li = fma(f, (double)d_i, (double)s0i);
             double xs, xc;
-            expj_small(kfs, fo, sck, xs, xc);
+            if constexpr (kWide) {
+                // -o takes any value (ref :1004-1005) and the AFC clamp (:303) first acts at the END of the
+                // call's second symbol: outside the polynomial's +/-2000 Hz range those two symbols take the
+                // full-range routine (their own instantiations; the steady-state body never tests for it)
+                if (__builtin_expect(uni_lt(2000.0, fabs(fo)), 0)) sincos(kfs * fo, &xs, &xc);
+                else expj_small(kfs, fo, sck, xs, xc);
+            } else {
+                expj_small(kfs, fo, sck, xs, xc);
+            }
             // Z = Lam * conj(X)
             const double zr = fma(lr, xc, li * xs);
             const double zi = fma(li, xc, -(lr * xs));
@@ -597,7 +611,13 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
         if (uni_lt(pos + 40.0 + 10.0, Nd)) {               // ref :221
             (void)housekeeping(pos);
             fetch(pos, true);
-            symbol(std::true_type{}, qp, qp);
+            symbol(TagFirst{}, qp, qp);
+            if (__builtin_expect(uni_lt(2000.0, fabs(fo)), 0) && uni_lt(pos + 40.0 + 10.0, Nd)) {
+                (void)housekeeping(pos);                   // an out-of-range -o is still in force for one more symbol
+                fetch(pos, false);
+                symbol(TagSecond{}, qq, qp);
+                qp = qq;
+            }
             // Batches: the end-of-call test and the tile events once, then as many symbols as are
             // provably clear of both. Every symbol fetches its successor's taps; across a batch
             // boundary that fetch is speculative (LDS only, harmless) and is repeated after the
@@ -607,10 +627,10 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 uint32_t pairs = uni(housekeeping(pos)) >> 1;
                 fetch(pos, false);
                 for (; pairs != 0u; --pairs) {
-                    symbol(std::false_type{}, qq, qp);
-                    symbol(std::false_type{}, qp, qq);
+                    symbol(TagSteady{}, qq, qp);
+                    symbol(TagSteady{}, qp, qq);
                 }
-                symbol(std::false_type{}, qq, qp);
+                symbol(TagSteady{}, qq, qp);
                 qp = qq;
             }
         }

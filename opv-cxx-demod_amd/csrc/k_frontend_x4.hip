@@ -305,6 +305,13 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_x4(OpvStream* __
                 // X[40] = exp(j 40 d): uniform per row, needed by the NEXT symbol's phase detector
                 double x40s, x40c;
                 expj_small((40.0 * kDeltaPerHz) * fo, x40s, x40c);
+                if (fabs(fo) > 2000.0) {
+                    // -o takes any value (ref :1004-1005) and the AFC clamp (:303) first acts at the END of the
+                    // call's second symbol: outside the polynomial's range those symbols take the full-range routine
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sincos((kfs0 + (16.0 * q) * kDeltaPerHz) * fo, &xs[q], &xc[q]);
+                    sincos((40.0 * kDeltaPerHz) * fo, &x40s, &x40c);
+                }
 
                 double o1 = 0, o2 = 0, o3 = 0, o4 = 0;             // on-time P1..P4 partials
                 double eA = 0, eB = 0, eC = 0, eD = 0, lA = 0, lB = 0, lC = 0, lD = 0;

@@ -101,6 +101,19 @@ def test_initial_offset_flag(amd, oracle, iq10):
     d.close()
 
 
+@pytest.mark.parametrize("off,alpha", [(6000.0, 0.001), (-2600.0, 0.001), (150000.0, 0.001), (300.0, 0.08), (0.0, 1.0)])
+def test_extreme_flag_values(amd, oracle, iq10, off, alpha):
+    """-o beyond the AFC clamp (the reference takes any value for the symbols before the first AFC update,
+    :1004-1005 / :302-303) and -a so large that the loop slams into its clamp every symbol."""
+    x = impair(iq10, amp=3000.0, f0_hz=400.0, ebn0_db=18.0, seed=77)
+    for frontend in (1, 4):
+        d = amd.Demod(1, max_samples=x.size // 2 + 64, streaming=True, init_offset=off, afc_alpha=alpha)
+        d.set_frontend(frontend)
+        got = d.receive([x])[0]
+        check_stream(amd, got, oracle.receive(x, streaming=True, init_offset=off, afc_alpha=alpha), f"-o {off} -a {alpha} x{frontend}")
+        d.close()
+
+
 def test_afc_alpha_flag(amd, oracle, iq10):
     d = amd.Demod(1, max_samples=iq10.size // 2 + 64, streaming=True, afc_alpha=0.01)
     got = d.receive([iq10])[0]
