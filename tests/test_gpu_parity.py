@@ -101,7 +101,8 @@ def test_initial_offset_flag(amd, oracle, iq10):
     d.close()
 
 
-@pytest.mark.parametrize("off,alpha", [(6000.0, 0.001), (-2600.0, 0.001), (150000.0, 0.001), (300.0, 0.08), (0.0, 1.0)])
+@pytest.mark.parametrize("off,alpha", [(6000.0, 0.001), (-2600.0, 0.001), (150000.0, 0.001), (300.0, 0.08), (0.0, 1.0),
+                                       (-700.0, 0.0), (100.0, -0.01)])
 def test_extreme_flag_values(amd, oracle, iq10, off, alpha):
     """-o beyond the AFC clamp (the reference takes any value for the symbols before the first AFC update,
     :1004-1005 / :302-303) and -a so large that the loop slams into its clamp every symbol."""
@@ -112,6 +113,20 @@ def test_extreme_flag_values(amd, oracle, iq10, off, alpha):
         got = d.receive([x])[0]
         check_stream(amd, got, oracle.receive(x, streaming=True, init_offset=off, afc_alpha=alpha), f"-o {off} -a {alpha} x{frontend}")
         d.close()
+
+
+@pytest.mark.parametrize("ppm", [-25000.0, -3000.0, 3000.0, 25000.0])
+def test_timing_loop_slipping(amd, oracle, iq10, ppm):
+    """Sample-clock errors far beyond what the timing loop can follow (0.3 % and 2.5 %): it slips a symbol
+    every few hundred / few dozen symbols and the TED output is large all the time; both mappings, -s and batch."""
+    x = impair(resample_clock(iq10, ppm), amp=5000.0, f0_hz=-300.0, ebn0_db=20.0, seed=9)
+    exp_s, exp_b = oracle.receive(x, streaming=True), oracle.receive(x, streaming=False)
+    for frontend in (1, 4):
+        for streaming, exp in ((True, exp_s), (False, exp_b)):
+            d = amd.Demod(1, max_samples=x.size // 2 + 64, streaming=streaming)
+            d.set_frontend(frontend)
+            check_stream(amd, d.receive([x])[0], exp, f"ppm {ppm} x{frontend} streaming={streaming}")
+            d.close()
 
 
 def test_afc_alpha_flag(amd, oracle, iq10):
