@@ -12,22 +12,26 @@
 // truncation per symbol with FMA contraction disabled. Given the same 2144 doubles this
 // kernel returns the same bytes, decisions and metric as the reference, always.
 //
-// Viterbi on a wave. metrics[64] live one per lane (int32, with the reference's 0x7FFFFFFF
-// sentinel logic, :805,:826-827). Step t: the four possible branch metrics are wave-uniform
-// (only (e1,e2) in {0,1}^2 exist); lane s selects the two it needs by its constant parity
-// pattern (G1=0x4F has no tap on state bit 5, G2=0x6D has, so the upper predecessor flips
-// e2 only), fetches the predecessor metrics from lanes s>>1 and (s>>1)+32 with ds_bpermute,
-// add-compare-selects with the reference's tie rule (m0 <= m1 -> lower predecessor, :829)
-// and the 64 decision bits of the step are one __ballot -> one 64-bit word in LDS
-// (1072 x 8 B = 8.6 KB/frame instead of the reference's 68.6 KB byte matrix). Traceback is a
-// serial walk over those words from the first-minimum end state (:835-843), emitting bytes
+// Viterbi on a wave: the 64 path metrics live one per lane (int32) under a ROTATING state-to-lane
+// map (state s at time t in lane rotr6(s, t)), which turns the trellis step into an XOR butterfly:
+// the two predecessors of the state a lane will hold are the lane itself and lane ^ (1 << k),
+// k = (5 - t) mod 6 - one DPP quad_perm / row shift / v_permlane*_swap per step, no LDS-crossbar
+// permute on the step's dependency chain. G1=0x4F has no tap on state bit 5, G2=0x6D has, so the
+// other predecessor flips e2 only; the own predecessor's (e1, e2) are per-lane constants for each of
+// the six phases. Add-compare-select with the reference's tie rule (m0 <= m1 -> lower predecessor,
+// :829); the 64 decision bits of a step are two ballots -> one 64-bit word in LDS (1072 x 8 B =
+// 8.6 KB/frame instead of the reference's 68.6 KB byte matrix). Traceback is a serial walk over those
+// words in lane space from the first-minimum end state (:835-843), emitting bytes
 // MSB-of-byte-133-first exactly as the packer does (:878-884), XORed with the LFSR table
 // (:887-895; the LFSR restarts at 0xFF every frame so it is a constant 134-byte table).
+// (The index algebra was checked against the oracle's decoder in a numpy model before it was written.)
 //
 // Bytes: 17 152 B of soft symbols in, 134 B out per frame (L2-resident right after the
 // front-end). Integer ACS rate: 68 608 ACS/frame. No MFMA.
 #include <hip/hip_runtime.h>
 #include <math.h>
+
+#include <type_traits>
 
 #include "opv_device.h"
 
@@ -67,11 +71,16 @@ __device__ inline void decode_one(const double* __restrict__ soft, uint32_t firs
                                   int32_t* __restrict__ metric_out, int8_t* tq, int8_t* td, uint8_t* tb,
                                   unsigned char* lds) {
     const int lane = threadIdx.x;
+    // LDS: the 2144 soft doubles are dead once quantised, so everything after them lives in their space.
+    // 17.3 KB per frame instead of 30 KB: nine frames per CU, i.e. two waves per SIMD - a lone wave per SIMD
+    // only gets every other issue slot when all four SIMDs of the CU are busy.
+    // s_q overlays the soft values it is computed from: lane l writes byte i = l + 64 it after ALL lanes of
+    // the wave have read soft[64 it .. 64 it + 63] (bytes >= 512 it), so nothing unread is overwritten.
     double* s_soft = reinterpret_cast<double*>(lds);                                 // 17 152 B
-    unsigned long long* s_dec = reinterpret_cast<unsigned long long*>(lds + 17152);  //  8 576 B
-    uint8_t* s_q = lds + 17152 + 8576;                                               //  2 144 B
-    uint8_t* s_d = s_q + OPV_CODED;                                                  //  2 144 B
-    uint8_t* s_out = s_d + OPV_CODED;                                                //    136 B
+    uint8_t* s_q = lds;                                                              //  2 144 B (over s_soft)
+    uint8_t* s_d = lds + OPV_CODED;                                                  //  2 144 B (after quantising)
+    unsigned long long* s_dec = reinterpret_cast<unsigned long long*>(lds + 2 * OPV_CODED);  // 8 576 B (4288 is 8-aligned)
+    uint8_t* s_out = lds + 17152;                                                    //    136 B
 
     for (int i = lane; i < OPV_CODED; i += 64) s_soft[i] = soft[(first + (uint32_t)i) & mask];  // ring or linear (mask = ~0)
     __syncthreads();
@@ -103,51 +112,100 @@ __device__ inline void decode_one(const double* __restrict__ soft, uint32_t firs
     }
     __syncthreads();
 
-    // ---- add-compare-select, 1072 steps (ref :810-833) ---------------------------------------
-    const int s = lane;
-    const int p0 = s >> 1, p1 = p0 + 32, inb = s & 1;
-    const int f0 = (inb << 6) | p0;
-    const bool e1 = __builtin_parity((unsigned)(f0 & 0x4F));  // same for both predecessors
-    const bool e2 = __builtin_parity((unsigned)(f0 & 0x6D));  // flipped for p1 (bit 5 of 0x6D)
-    int metric = (s == 0) ? 0 : 0x7FFFFFFF;                   // ref :805-806
+    // ---- add-compare-select, 1072 steps (ref :810-833), as XOR butterflies ----------------------
+    // The metric of state s at time t lives in lane rotr6(s, t): the predecessors (s>>1) and (s>>1)+32
+    // (:815-816) of the state that will sit in lane l at time t+1 are then lane l ITSELF and lane
+    // l ^ (1 << k), k = (5 - t) mod 6 - one DPP / permlane move per step instead of two LDS-crossbar
+    // permutes on the step's critical path. Bit k of l is the state's input bit (:817) and tells which
+    // of the two is the lower predecessor p0 (ties keep p0, :829). The expected code bits of the own
+    // predecessor are per-lane constants for each of the six phases; 7 - x == x ^ 7 for 3-bit x.
+    // Unreachable states carry 0x3FFFFFF0 instead of the reference's saturating 0x7FFFFFFF (:826-827):
+    // they vanish after six steps, never win against a reachable one (finite metrics stay below 15 008),
+    // and their decisions are never visited by the traceback.
+    int m1c[6], m2c[6];
+#pragma unroll
+    for (int ph = 0; ph < 6; ++ph) {
+        const int r = (ph + 1) % 6;
+        const int st = r ? (((lane << r) | (lane >> (6 - r))) & 63) : lane;   // state in this lane at time t+1
+        const int b0 = st & 1, pown = (st >> 1) | (b0 << 5), f = (b0 << 6) | pown;
+        m1c[ph] = __builtin_parity((unsigned)(f & 0x4F)) ? 7 : 0;
+        m2c[ph] = __builtin_parity((unsigned)(f & 0x6D)) ? 7 : 0;
+    }
+    int metric = (lane == 0) ? 0 : 0x3FFFFFF0;                   // ref :805-806
     const uint16_t* s_d2 = reinterpret_cast<const uint16_t*>(s_d);
-#pragma unroll 4
-    for (int t = 0; t < OPV_FBITS; ++t) {
-        const unsigned pair = s_d2[t];  // sg1 | sg2<<8, wave-uniform LDS broadcast
+    auto acs = [&](auto phase_tag, int t) {
+        constexpr int PH = decltype(phase_tag)::value;
+        constexpr int K = (5 - PH + 6) % 6;
+        constexpr unsigned long long kB0 = K == 0 ? 0xAAAAAAAAAAAAAAAAull : K == 1 ? 0xCCCCCCCCCCCCCCCCull
+                                         : K == 2 ? 0xF0F0F0F0F0F0F0F0ull : K == 3 ? 0xFF00FF00FF00FF00ull
+                                         : K == 4 ? 0xFFFF0000FFFF0000ull : 0xFFFFFFFF00000000ull;
+        const unsigned pair = (unsigned)__builtin_amdgcn_readfirstlane((int)s_d2[t]);  // sg1 | sg2<<8, wave-uniform
         const int sg1 = (int)(pair & 0xFF), sg2 = (int)(pair >> 8);
-        const int b1 = e1 ? 7 - sg1 : sg1;                    // ref :823-824
-        const int bm0 = b1 + (e2 ? 7 - sg2 : sg2);
-        const int bm1 = b1 + (e2 ? sg2 : 7 - sg2);
-        const int mp0 = __shfl(metric, p0, 64);
-        const int mp1 = __shfl(metric, p1, 64);
-        const int m0 = (mp0 < 0x7FFFFFF0) ? mp0 + bm0 : 0x7FFFFFFF;  // ref :826-827
-        const int m1 = (mp1 < 0x7FFFFFF0) ? mp1 + bm1 : 0x7FFFFFFF;
-        const bool take1 = !(m0 <= m1);                       // ref :829: ties keep p0
-        metric = take1 ? m1 : m0;
-        const unsigned long long word = __ballot(take1);
+        const int b1 = m1c[PH] ^ sg1, c = m2c[PH] ^ sg2;         // ref :823-824
+        int mp;                                                   // metric held by lane ^ (1 << K)
+        if constexpr (K == 0) mp = __builtin_amdgcn_mov_dpp(metric, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+        else if constexpr (K == 1) mp = __builtin_amdgcn_mov_dpp(metric, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+        else if constexpr (K == 2) {
+            mp = __builtin_amdgcn_update_dpp(0, metric, 0x104, 0xF, 0x5, false);                    // row_shl:4 -> banks 0,2
+            mp = __builtin_amdgcn_update_dpp(mp, metric, 0x114, 0xF, 0xA, false);                   // row_shr:4 -> banks 1,3
+        } else if constexpr (K == 3) mp = __builtin_amdgcn_mov_dpp(metric, 0x128, 0xF, 0xF, true); // row_ror:8
+        else if constexpr (K == 4) {
+            auto r = __builtin_amdgcn_permlane16_swap((unsigned)metric, (unsigned)metric, false, false);
+            mp = (lane & 16) ? (int)r[0] : (int)r[1];
+        } else {
+            auto r = __builtin_amdgcn_permlane32_swap((unsigned)metric, (unsigned)metric, false, false);
+            mp = (lane & 32) ? (int)r[0] : (int)r[1];
+        }
+        const int own = metric + b1 + c;
+        const int oth = mp + b1 + (7 - c);
+        const unsigned long long gt = __ballot(own > oth), lt = __ballot(own < oth);
+        metric = own < oth ? own : oth;
+        const unsigned long long word = (gt & ~kB0) | (lt & kB0);  // 1 = upper predecessor taken (:829-831)
         if (lane == 0) s_dec[t] = word;
+    };
+    {
+        int t = 0;
+        for (; t + 6 <= OPV_FBITS; t += 6) {
+            acs(std::integral_constant<int, 0>{}, t);
+            acs(std::integral_constant<int, 1>{}, t + 1);
+            acs(std::integral_constant<int, 2>{}, t + 2);
+            acs(std::integral_constant<int, 3>{}, t + 3);
+            acs(std::integral_constant<int, 4>{}, t + 4);
+            acs(std::integral_constant<int, 5>{}, t + 5);
+        }
+        static_assert(OPV_FBITS % 6 == 4, "tail below handles four steps");
+        acs(std::integral_constant<int, 0>{}, t);
+        acs(std::integral_constant<int, 1>{}, t + 1);
+        acs(std::integral_constant<int, 2>{}, t + 2);
+        acs(std::integral_constant<int, 3>{}, t + 3);
     }
     __syncthreads();
 
-    // ---- best end state: first minimum (ref :835-837) ----------------------------------------
-    int bm = metric, bs = s;
+    // ---- best end state: first minimum in STATE order (ref :835-837) ---------------------------
+    constexpr int kEndRot = OPV_FBITS % 6;                       // lane l holds state rotl6(l, 4) at the end
+    int bm = metric, bs = ((lane << kEndRot) | (lane >> (6 - kEndRot))) & 63, bl = lane;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        const int om = __shfl_xor(bm, off, 64), os = __shfl_xor(bs, off, 64);
-        if (om < bm || (om == bm && os < bs)) { bm = om; bs = os; }
+        const int om = __shfl_xor(bm, off, 64), os = __shfl_xor(bs, off, 64), ol = __shfl_xor(bl, off, 64);
+        if (om < bm || (om == bm && os < bs)) { bm = om; bs = os; bl = ol; }
     }
 
     // ---- traceback + pack + derandomise (ref :839-843, :878-895), uniform on all lanes ---------
-    int cur = bs;
+    // in lane space: the decoded bit is bit k of the current lane, the predecessor's lane has that bit
+    // replaced by the decision
+    int cur = bl;
+    int k = (5 - (OPV_FBITS - 1) % 6 + 6) % 6;
     for (int i = 0; i < OPV_FB; ++i) {
         unsigned byte = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int t = OPV_FBITS - 1 - 8 * i - j;
-            byte |= (unsigned)(cur & 1) << j;                 // bits[t] = s % 2 -> bit j of byte i
-            if (tb && lane == 0) tb[t] = (uint8_t)(cur & 1);
+            const unsigned b = (unsigned)(cur >> k) & 1u;         // bits[t] = s % 2 -> bit j of byte i
+            byte |= b << j;
+            if (tb && lane == 0) tb[t] = (uint8_t)b;
             const unsigned d = (unsigned)((s_dec[t] >> cur) & 1ull);
-            cur = (cur >> 1) + (d ? 32 : 0);
+            cur ^= (int)((b ^ d) << k);
+            k = (k == 5) ? 0 : k + 1;                             // k(t-1) = k(t) + 1 mod 6
         }
         if (lane == 0) s_out[i] = (uint8_t)(byte ^ kLfsr.b[i]);
     }
@@ -156,7 +214,8 @@ __device__ inline void decode_one(const double* __restrict__ soft, uint32_t firs
     if (lane == 0) *metric_out = bm;
 }
 
-constexpr int kDecodeLds = 17152 + 8576 + 2 * OPV_CODED + 144;
+constexpr int kDecodeLds = 17152 + 144;
+static_assert(2 * OPV_CODED % 8 == 0 && 2 * OPV_CODED + 8 * OPV_FBITS <= 17152, "decision words fit behind s_q / s_d");
 
 }  // namespace
 
