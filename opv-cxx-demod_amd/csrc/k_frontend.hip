@@ -230,6 +230,8 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
     // Loop constants parked in VGPRs: one wave per SIMD has registers to spare, while hipcc
     // otherwise keeps re-forming 64-bit literals in SGPR pairs inside the loop.
     double kc_tfmax = 0.1, kc_beta = 0.00001, kc_alpha = 0.005, kc_fomax = 2000.0, kc_eps = 1e-10;
+    double kc_tiny = 1e-100;
+    asm volatile("" : "+v"(kc_tiny));
     double kc_halfpi = 1.57079632679489661923, kc_32 = 32.0, kc_m1_32 = -1.0 / 32.0, kc_gain = st.afc_alpha * (kSymRate / kTwoPi);
     asm volatile("" : "+v"(kc_tfmax), "+v"(kc_beta), "+v"(kc_alpha), "+v"(kc_fomax), "+v"(kc_eps));
     asm volatile("" : "+v"(kc_halfpi), "+v"(kc_32), "+v"(kc_m1_32), "+v"(kc_gain));
@@ -479,7 +481,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             const double wEr = fma(szi, bE, eA), wEi = fma(-szr, bE, eB);
             const double wLr = fma(szi, bL, lA), wLi = fma(-szr, bL, lB);
             double ted, pd = 0.0;
-            [[maybe_unused]] double dr = 0, di = 0, cx = 0, cy = 0, ax = 0, ay = 0, mx = 1.0, mn = 0, ratio = 0;
+            [[maybe_unused]] double dr = 0, di = 0, cx = 0, cy = 0, ax = 0, ay = 0, mx = 1.0, mn = 0, ratio = 0, dm_ = 1.0;
             [[maybe_unused]] double2 c01{0, 0}, c23{0, 0}, c45{0, 0}, c67{0, 0};
             [[maybe_unused]] double c8 = 0, h = 0;
             double q2;
@@ -528,8 +530,10 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 __builtin_amdgcn_sched_barrier(0);
                 cx = fma(ar, prv.x40s, -t_cx);                      // Re z
                 ax = fabs(cx); ay = fabs(cy);
-                mx = fmax(ax, ay);
-                mn = fmin(ax, ay);
+                // max / min of the magnitudes with source modifiers (fmax(fabs(x), ..) costs a separate
+                // canonicalising v_max_f64 |x|, |x| first)
+                asm("v_max_f64 %0, |%3|, |%4|\n\tv_min_f64 %1, |%3|, |%4|\n\tv_max_f64 %2, %0, %5"
+                    : "=&v"(mx), "=&v"(mn), "=&v"(dm_) : "v"(cx), "v"(cy), "v"(kc_tiny));
             }
             const double Eim = readlane_d(q2, 16), Lim = readlane_d(q2, 48);
             const double Ere = readlane_d(q2, 0), Lre = readlane_d(q2, 32);
@@ -547,7 +551,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             } else {
                 // the two divides of the symbol on one reciprocal: ted and mn/mx for the phase
                 // detector; den in [1e-10, 2e12], dm in [1e-100, 1e12]
-                const double dm = fmax(mx, 1e-100);                 // digital silence: 0/1e-100 = 0, fixed up below
+                const double dm = dm_;                              // max(mx, 1e-100); digital silence: 0/1e-100 = 0, fixed up below
                 const double tt = den * dm;
                 double y = __builtin_amdgcn_rcp(tt);
                 y = fma(fma(-tt, y, 1.0), y, y);
@@ -560,8 +564,10 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 const double kd = rint(ratio * kc_32);              // nearest expansion point k/32, k = 0..32
                 const int k = (int)kd;
                 h = fma(kd, kc_m1_32, ratio);                       // |h| <= 1/64
-                const double2* trow = reinterpret_cast<const double2*>(atab + k * (int)kTabRow);
-                c8 = atab[k * (int)kTabRow + 8]; c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
+                // row address by the full-rate 24-bit multiply (v_mul_lo_u32 is a quarter-rate instruction)
+                const unsigned char* rowb = reinterpret_cast<const unsigned char*>(atab) + __umul24((unsigned)k, kTabRow * 8u);
+                const double2* trow = reinterpret_cast<const double2*>(rowb);
+                c8 = reinterpret_cast<const double*>(rowb)[8]; c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
                 ted = num * iden;
                 ted = fma(fma(-den, ted, num), iden, ted);
             }
@@ -602,7 +608,12 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 if (__builtin_expect(uni_eq(mx, 0.0), 0))           // digital silence on either side
                     pd = silence_pd(dr, di, prv, soft < 0.0, fo_sum, n_soft + (((my_soft_off - soft_off0) & soft_bmask) >> 3));
             }
-            if constexpr (!kFirst) fo = clampd(fma(kc_gain, pd, fo), kc_nfomax, kc_fomax);  // ref :300-303
+            if constexpr (!kFirst) {                                // ref :300-303
+                // (written as instructions: through fmin/fmax hipcc re-canonicalises the two loop-invariant
+                // bounds with a v_max_f64 x, x each, every symbol)
+                const double fo_new = fma(kc_gain, pd, fo);
+                asm("v_max_f64 %0, %1, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(fo) : "v"(fo_new), "v"(kc_nfomax), "v"(kc_fomax));
+            }
             fo_sum = fo_sum_next;                                   // (the silence rule above needs the sum BEFORE this symbol)
             // prev <- this symbol's on-time correlations (ref :309-310)
             cur.a = P1o; cur.b = P2o; cur.c = P3o; cur.d = P4o;
