@@ -80,6 +80,7 @@ __global__ void k_fill_i32(int32_t* p, int32_t v, size_t n) {
 
 struct HostStream {
     int16_t* d_iq_owned = nullptr;  // push path buffer
+    int16_t* d_iq_alt = nullptr;    // second buffer of the same size: compaction copies the retained tail across and swaps
     size_t iq_cap = 0;              // samples
     const int16_t* d_iq = nullptr;  // what the kernels read
     uint64_t n_avail = 0;
@@ -276,8 +277,10 @@ extern "C" void opv_destroy(opv_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    for (auto& h : c->hs)
+    for (auto& h : c->hs) {
         if (h.d_iq_owned) (void)hipFree(h.d_iq_owned);
+        if (h.d_iq_alt) (void)hipFree(h.d_iq_alt);
+    }
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_counts, c->d_tx_phases};
@@ -299,31 +302,26 @@ static int check_stream(opv_ctx* c, int s) {
 // alignment). The soft-symbol log and the frame / event / chunk records are rings on the device
 // and need no host action. Indices handed to the caller stay absolute.
 static int compact_stream(opv_ctx* c, int s) {
-    if (int r = c->refresh()) return r;  // synchronises: no kernel is touching the buffers
+    if (int r = c->refresh()) return r;  // synchronises (once per round: the mirror stays valid for the other streams)
     HostStream& h = c->hs[s];
     OpvStream st = c->mirror[s];
-    bool changed = false;
     const uint64_t keep = st.origin >= 16 ? ((st.origin - 16) & ~3ull) : 0;
-    if (keep > 0 && h.d_iq_owned) {
-        const uint64_t len = h.n_avail - keep;  // samples to retain (less than two chunks in steady state)
-        int16_t* tmp = nullptr;
-        if (len) {
-            HIPCHK(hipMalloc(&tmp, len * 4));
-            HIPCHK(hipMemcpy(tmp, h.d_iq_owned + 2 * keep, len * 4, hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(h.d_iq_owned, tmp, len * 4, hipMemcpyDeviceToDevice));
-            HIPCHK(hipFree(tmp));
-        }
-        h.n_avail -= keep;
-        h.last_round_avail = h.last_round_avail > keep ? h.last_round_avail - keep : 0;
-        st.origin -= keep;
-        st.n_avail = h.n_avail;
-        st.iq_base += keep;
-        changed = true;
-    }
-    if (changed) {
-        HIPCHK(hipMemcpy(c->d_streams + s, &st, sizeof st, hipMemcpyHostToDevice));
-        c->mirror[s] = st;
-    }
+    if (keep == 0 || !h.d_iq_owned) return OPV_OK;
+    const uint64_t len = h.n_avail - keep;  // samples to retain (less than two chunks in steady state)
+    if (!h.d_iq_alt) HIPCHK(hipMalloc(&h.d_iq_alt, h.iq_cap * 4 + 16384));
+    // tail -> head of the other buffer, in stream order before the next kernels; later pushes write behind it
+    if (len) HIPCHK(hipMemcpyAsync(h.d_iq_alt, h.d_iq_owned + 2 * keep, len * 4, hipMemcpyDeviceToDevice, c->stream));
+    std::swap(h.d_iq_owned, h.d_iq_alt);
+    h.d_iq = h.d_iq_owned;
+    h.n_avail -= keep;
+    h.last_round_avail = h.last_round_avail > keep ? h.last_round_avail - keep : 0;
+    h.dirty = true;
+    st.iq = h.d_iq;
+    st.origin -= keep;
+    st.n_avail = h.n_avail;
+    st.iq_base += keep;
+    c->mirror[s] = st;  // the mirror is the staging area of this (pageable -> device, staged at once) copy
+    HIPCHK(hipMemcpyAsync(c->d_streams + s, &c->mirror[s], sizeof st, hipMemcpyHostToDevice, c->stream));
     return OPV_OK;
 }
 
@@ -470,9 +468,11 @@ extern "C" int opv_reset_stream(opv_ctx* c, int s) {
     for (int i = lo; i < hi; ++i) {
         HostStream& h = c->hs[i];
         int16_t* keep = h.d_iq_owned;
+        int16_t* keep_alt = h.d_iq_alt;
         const size_t cap = h.iq_cap;
         h = HostStream();
         h.d_iq_owned = keep;
+        h.d_iq_alt = keep_alt;
         h.iq_cap = cap;
         h.d_iq = keep;
     }
