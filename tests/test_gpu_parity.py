@@ -704,17 +704,18 @@ def test_host_cli_process_contract(amd, golden, iq10):
     assert p.returncode == 2 and p.stdout == b"" and b"coherent" in p.stderr
 
 
-def test_clock_rate_error_and_random_channels_fuzz(amd, oracle, iq10, iq100):
+@pytest.mark.parametrize("seed", [20261003 + k for k in range(int(os.environ.get("OPV_FUZZ_SEEDS", "1")))])
+def test_clock_rate_error_and_random_channels_fuzz(amd, oracle, iq10, iq100, seed):
     """Differential fuzz: 24 streams in one context, each with its own sample-clock error (the timing
     loop then drifts through integer sample boundaries, the chunk grid moves: leftovers from 18 to 50), carrier offset, level, Eb/N0 and a random truncation point; both -s and batch mode."""
-    rng = np.random.default_rng(20261003)
+    rng = np.random.default_rng(seed)
     caps = []
     for k in range(24):
         base = iq100[: 2 * 86720 * 14] if k % 3 == 0 else iq10
         ppm = float(rng.choice([-400.0, -120.0, -35.0, 0.0, 7.0, 60.0, 250.0, 900.0]))
         x = resample_clock(base, ppm) if ppm else base
         x = impair(x, amp=float(rng.uniform(300, 9000)), f0_hz=float(rng.uniform(-2100, 2100)),
-                   ebn0_db=float(rng.uniform(9, 24)), seed=100 + k)
+                   ebn0_db=float(rng.uniform(9, 24)), seed=seed % 1000 + k)
         cut = int(rng.integers(x.size // 4, x.size // 2)) if k % 4 == 1 else x.size // 2
         caps.append(x[: 2 * cut])
     nmax = max(c.size // 2 for c in caps)
