@@ -86,7 +86,11 @@ int main(int argc, char** argv) {
     if (!quiet) fprintf(stderr, "opv-rx-bridge: %d stream(s) -> udp://%s:%d..%d\n", S, host.c_str(), base_port, base_port + S - 1);
 
     std::vector<pollfd> pfd(S);
-    std::vector<unsigned char> buf(16384 + 4);
+    constexpr size_t kRead = 16384;                       // opv-modem's read size (src/opv-modem.cpp:734,753)
+    std::vector<unsigned char> bufs((size_t)S * (kRead + 4));   // one read buffer per stream: a poll round is ONE batched push
+    std::vector<int> ids;
+    std::vector<const int16_t*> ptrs;
+    std::vector<size_t> lens;
     uint8_t frames[64 * OPV_FRAME_BYTES];
     opv_frame_meta meta[64];
     int open_streams = S;
@@ -110,11 +114,13 @@ int main(int argc, char** argv) {
         for (int k = 0; k < S; ++k) { pfd[k].fd = in[k].eof ? -1 : in[k].fd; pfd[k].events = POLLIN; pfd[k].revents = 0; }
         if (poll(pfd.data(), S, 10) < 0) break;  // 10 ms like the reference's select timeout
         bool any = false;
+        ids.clear(); ptrs.clear(); lens.clear();
         for (int k = 0; k < S; ++k) {
             if (in[k].eof) continue;
             if (!(pfd[k].revents & (POLLIN | POLLHUP))) continue;
-            memcpy(buf.data(), in[k].carry, in[k].ncarry);
-            const ssize_t r = read(in[k].fd, buf.data() + in[k].ncarry, 16384);
+            unsigned char* buf = bufs.data() + (size_t)k * (kRead + 4);
+            memcpy(buf, in[k].carry, in[k].ncarry);
+            const ssize_t r = read(in[k].fd, buf + in[k].ncarry, kRead);
             if (r < 0) continue;  // EAGAIN
             if (r == 0) {
                 in[k].eof = true;
@@ -124,14 +130,15 @@ int main(int argc, char** argv) {
                 continue;
             }
             const size_t have = in[k].ncarry + (size_t)r, ns = have / 4;
-            if (ns && opv_push_iq(ctx, k, reinterpret_cast<const int16_t*>(buf.data()), ns) < 0) {
-                fprintf(stderr, "opv-rx-bridge: stream %d: %s\n", k, opv_last_error());
-                return 2;
-            }
+            if (ns) { ids.push_back(k); ptrs.push_back(reinterpret_cast<const int16_t*>(buf)); lens.push_back(ns); }
             in[k].samples += ns;
             in[k].ncarry = have - ns * 4;
-            memcpy(in[k].carry, buf.data() + ns * 4, in[k].ncarry);
+            memcpy(in[k].carry, buf + ns * 4, in[k].ncarry);
             any = true;
+        }
+        if (!ids.empty() && opv_push_iq_batch(ctx, (int)ids.size(), ids.data(), ptrs.data(), lens.data()) < 0) {
+            fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error());
+            return 2;
         }
         if (any && drain() < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
     }
