@@ -200,6 +200,12 @@ long opv_tx_modulate_device(opv_ctx* ctx, const uint8_t* frames134, size_t n_fra
  * noise from a counter-based generator keyed by (seed, n). d_in/d_out: device int16 IQ. */
 int opv_channel_device(opv_ctx* ctx, const int16_t* d_in, int16_t* d_out, size_t n_samples,
                        double gain, double f0_hz, double sigma, uint64_t seed);
+/* Sample-clock error for the same tool chain: d_out[n] = rint(linear interpolation of d_in
+ * at n (1 + clock_ppm 1e-6)), i.e. the capture as an ADC running clock_ppm parts per million fast would have
+ * taken it. Returns the number of samples written, floor(n_in / (1 + clock_ppm 1e-6)) <= out_capacity, or a
+ * negative error. Asynchronous on the context's stream like opv_channel_device. */
+long opv_resample_device(opv_ctx* ctx, const int16_t* d_in, size_t n_in, int16_t* d_out, size_t out_capacity,
+                         double clock_ppm);
 
 #ifdef __cplusplus
 }

@@ -4,6 +4,9 @@
 //   out[n] = clip(rint(gain * in[n] * exp(j 2 pi f0 n / Fs) + sigma * (N(0,1) + j N(0,1))))
 // Noise is counter-based (keyed by seed and the sample index) so a stream is reproducible
 // on any device and independent of the launch geometry.
+// k_resample_clock adds the sample-clock error of SURVEY.md §8f-2: the capture as an ADC running
+// `ppm` parts per million fast would have taken it (linear interpolation at n (1 + ppm 1e-6), round to
+// nearest) - what makes the timing loop drift through sample boundaries and move the chunk grid.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -57,5 +60,22 @@ extern "C" __global__ __launch_bounds__(256) void k_channel(const int4* __restri
             r[k] = pack_iq(yr, yi);
         }
         out[q] = make_int4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+// out[n] = rint(lerp(in, n * rate)), rate = 1 + ppm 1e-6, index clamped to n_in - 2 (the last output samples).
+// Same operations in the same order as the numpy model the parity tests use (tests/oracle_lib.py
+// resample_clock; contraction is off for this TU), so the two are bit-identical.
+extern "C" __global__ __launch_bounds__(256) void k_resample_clock(const int* __restrict__ in, uint64_t n_in,
+                                                                    int* __restrict__ out, uint64_t n_out, double rate) {
+    for (uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; n < n_out; n += (uint64_t)gridDim.x * blockDim.x) {
+        const double t = (double)n * rate;
+        uint64_t i = (uint64_t)t;
+        if (i > n_in - 2) i = n_in - 2;
+        const double f = t - (double)i, g = 1.0 - f;
+        const int w0 = in[i], w1 = in[i + 1];
+        const double re = (double)(int)(short)(w0 & 0xFFFF) * g + (double)(int)(short)(w1 & 0xFFFF) * f;
+        const double im = (double)(w0 >> 16) * g + (double)(w1 >> 16) * f;
+        out[n] = pack_iq(re, im);
     }
 }

@@ -24,6 +24,7 @@ extern "C" __global__ void k_sync_track(OpvStream*);
 extern "C" __global__ void k_frame_decode(OpvStream*);
 extern "C" __global__ void k_decode_payloads(const double*, uint32_t, uint8_t*, int32_t*, int8_t*, int8_t*, uint8_t*);
 extern "C" __global__ void k_channel(const int4*, int4*, uint64_t, double, double, double, uint64_t);
+extern "C" __global__ void k_resample_clock(const int*, uint64_t, int*, uint64_t, double);
 extern "C" __global__ void k_tx_modulate(const int8_t*, const double2*, uint64_t, int*, uint32_t*, uint64_t*, uint32_t);
 
 namespace {
@@ -712,6 +713,23 @@ extern "C" int opv_channel_device(opv_ctx* c, const int16_t* d_in, int16_t* d_ou
     k_channel<<<blocks, 256, 0, c->stream>>>((const int4*)d_in, (int4*)d_out, quads, gain, f0_hz / 2168000.0, sigma, seed);
     HIPCHK(hipGetLastError());
     return OPV_OK;
+}
+
+extern "C" long opv_resample_device(opv_ctx* c, const int16_t* d_in, size_t n_in, int16_t* d_out, size_t out_cap,
+                                    double clock_ppm) {
+    if (!c || !d_in || !d_out) return fail(OPV_EINVAL, "null argument");
+    if (n_in < 2) return fail(OPV_EINVAL, "opv_resample_device: at least two input samples");
+    if (!(clock_ppm > -5e5 && clock_ppm < 5e5)) return fail(OPV_EINVAL, "opv_resample_device: |clock_ppm| must be below 5e5");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const double rate = 1.0 + clock_ppm * 1e-6;
+    const uint64_t n_out = (uint64_t)((double)n_in / rate);
+    if (n_out > out_cap) return fail(OPV_ECAPACITY, "opv_resample_device: output buffer too small");
+    if (n_out == 0) return 0;
+    unsigned blocks = (unsigned)((n_out + 255) / 256);
+    if (blocks > 256u * 8u) blocks = 256u * 8u;
+    k_resample_clock<<<blocks, 256, 0, c->stream>>>((const int*)d_in, (uint64_t)n_in, (int*)d_out, n_out, rate);
+    HIPCHK(hipGetLastError());
+    return (long)n_out;
 }
 
 extern "C" long opv_tx_modulate_device(opv_ctx* c, const uint8_t* frames, size_t n_frames, int16_t* d_iq_out) {

@@ -32,7 +32,7 @@ EXPORTS = [
     "opv_attach_device_iq", "opv_process", "opv_sync", "opv_set_frontend", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_tap_soft", "opv_tap_chunks",
     "opv_tap_offset_energies", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_modulated_samples",
-    "opv_tx_modulate", "opv_channel_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device",
+    "opv_tx_modulate", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device",
 ]
 
 
@@ -125,6 +125,8 @@ def lib():
         L.opv_tx_modulate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.opv_channel_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double,
                                          C.c_double, C.c_uint64]
+        L.opv_resample_device.restype = C.c_long
+        L.opv_resample_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_double]
         L.opv_enable_timing.argtypes = [C.c_void_p, C.c_int]
         L.opv_tx_modulate_device.restype = C.c_long
         L.opv_tx_modulate_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -286,6 +288,12 @@ class Demod:
     def channel(self, d_in, d_out, n_samples, gain=1.0, f0_hz=0.0, sigma=0.0, seed=0):
         _chk(lib().opv_channel_device(self.h, C.c_void_p(d_in), C.c_void_p(d_out), n_samples, gain, f0_hz, sigma,
                                       seed))
+
+    def resample(self, d_in, n_in, d_out, out_cap, clock_ppm):
+        """opv_resample_device: returns the number of samples written to d_out"""
+        n = lib().opv_resample_device(self.h, C.c_void_p(d_in), n_in, C.c_void_p(d_out), out_cap, clock_ppm)
+        _chk(n)
+        return n
 
     # convenience: the whole reference main() for one host capture on stream 0..n-1
     def receive(self, captures):

@@ -838,3 +838,40 @@ def test_push_batch_and_pooled_pops(amd, oracle, iq10):
         a, _ = soft_err(d.soft(k), exp["soft"])
         assert a < SOFT_TIGHT, (k, a)
     d.close()
+
+
+def test_device_clock_error_tool(amd, oracle, iq10):
+    """the device channel chain with a sample-clock error. opv_resample_device is bit-identical
+    to the numpy model the CPU-side tests use; modulate -> resample -> channel -> receive stays in HBM and the
+    receiver's output on those captures equals the oracle's on the same bytes."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = iq10.size // 2
+    d_in = torch.from_numpy(iq10).to(dev)
+    d = amd.Demod(4, max_samples=n + 4096, streaming=True)
+    caps = []
+    for ppm in (-350.0, -20.0, 45.0, 700.0):
+        d_rs = torch.zeros(2 * (n + 2048), dtype=torch.int16, device=dev)
+        n_out = d.resample(d_in.data_ptr(), n, d_rs.data_ptr(), n + 2048, ppm)
+        d.sync()
+        model = resample_clock(iq10, ppm)
+        assert n_out == model.size // 2
+        assert np.array_equal(d_rs[: 2 * n_out].cpu().numpy(), model), ppm     # same operations, same order
+        n4 = n_out & ~3
+        d_ch = torch.empty(2 * n4, dtype=torch.int16, device=dev)
+        d.channel(d_rs.data_ptr(), d_ch.data_ptr(), n4, gain=0.2, f0_hz=123.0 * ppm / 45.0, sigma=300.0, seed=int(1000 + ppm))
+        d.sync()
+        caps.append(d_ch)
+    for k, c in enumerate(caps):
+        d.attach(k, c.data_ptr(), c.numel() // 2, eof=True)
+    d.process()
+    d.sync()
+    for k, c in enumerate(caps):
+        x = c.cpu().numpy()
+        exp = oracle.receive(x, streaming=True)
+        fr, meta = d.pop_frames(k)
+        assert np.array_equal(fr, exp["frames"]) and len(fr) >= 9, k
+        assert np.array_equal(meta["viterbi_metric"], exp["metrics"]) and np.array_equal(meta["release_symbol"], exp["frame_sym"]), k
+        a, _ = soft_err(d.soft(k), exp["soft"])
+        assert a < SOFT_TIGHT, (k, a)
+    d.close()
