@@ -875,3 +875,33 @@ def test_device_clock_error_tool(amd, oracle, iq10):
         a, _ = soft_err(d.soft(k), exp["soft"])
         assert a < SOFT_TIGHT, (k, a)
     d.close()
+
+
+@pytest.mark.parametrize("frontend", [1, 4])
+def test_every_tiny_tail_and_tiny_capture(amd, oracle, iq10, frontend):
+    """Tail calls of 0, 1, 2, 3 symbols (one full chunk + 0..130 samples) in -s mode, and whole captures of
+    30..300 samples in batch mode (offset search over a handful of symbols): every length, one stream each."""
+    x = impair(iq10, amp=4000.0, f0_hz=650.0, ebn0_db=20.0, seed=21)
+    lens = [86720 + r for r in range(0, 131)]
+    d = amd.Demod(len(lens), max_samples=88000, streaming=True)
+    d.set_frontend(frontend)
+    got = d.receive([x[: 2 * n] for n in lens])
+    d.close()
+    for n, g in zip(lens, got):
+        e = oracle.receive(x[: 2 * n], streaming=True)
+        assert g["state"].total_symbols == e["n_soft"], n
+        assert g["chunks"].shape == e["chunks"].shape and np.allclose(g["chunks"], e["chunks"], rtol=0, atol=1e-9), n
+        a, _ = soft_err(g["soft"], e["soft"])
+        assert a < SOFT_TIGHT, (n, a)
+    lens = list(range(30, 301, 3))
+    d = amd.Demod(len(lens), max_samples=1024, streaming=False)
+    d.set_frontend(frontend)
+    got = d.receive([x[: 2 * n] for n in lens])
+    d.close()
+    for n, g in zip(lens, got):
+        e = oracle.receive(x[: 2 * n], streaming=False)
+        assert g["state"].total_symbols == e["n_soft"], n
+        assert g["state"].est_offset_hz == e["est_offset"], (n, g["state"].est_offset_hz, e["est_offset"])
+        if e["n_soft"]:
+            a, _ = soft_err(g["soft"], e["soft"])
+            assert a < SOFT_TIGHT, (n, a)
