@@ -905,3 +905,60 @@ def test_every_tiny_tail_and_tiny_capture(amd, oracle, iq10, frontend):
         if e["n_soft"]:
             a, _ = soft_err(g["soft"], e["soft"])
             assert a < SOFT_TIGHT, (n, a)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3] + list(range(4, 4 + 3 * (int(os.environ.get("OPV_FUZZ_SEEDS", "1")) - 1))))
+def test_random_call_sequences(amd, oracle, iq10, seed):
+    """Randomised use of the boundary: pushes of random sizes to random streams (singly or batched), opv_process
+    at random moments, pops of random streams in between, a staging buffer small enough to be compacted every
+    few chunks. Whatever the interleaving, each stream's frames, metadata and tracker events are the oracle's."""
+    rng = np.random.default_rng(seed)
+    S = 6
+    caps = [impair(iq10, amp=float(rng.uniform(800, 6000)), f0_hz=float(rng.uniform(-1900, 1900)),
+                   ebn0_db=float(rng.uniform(11, 22)), seed=seed * 50 + k) for k in range(S)]
+    d = amd.Demod(S, max_samples=3 * 86720 + 70000, streaming=True)
+    if seed % 3 == 0:
+        d.set_frontend(4)
+    at = [0] * S
+    frames = [[] for _ in range(S)]
+    metas = [[] for _ in range(S)]
+    events = [[] for _ in range(S)]
+    since = [0] * S          # samples pushed to a stream since the last process (must stay within the staging buffer)
+
+    def pop(k):
+        fr, meta = d.pop_frames(k)
+        frames[k].append(fr); metas[k].append(meta); events[k].append(d.pop_events(k))
+
+    while any(a < c.size // 2 for a, c in zip(at, caps)):
+        act = rng.integers(0, 10)
+        if act < 6:
+            ks = [int(k) for k in rng.choice(S, size=int(rng.integers(1, 4)), replace=False) if at[k] < caps[k].size // 2]
+            ks = [k for k in ks if since[k] < 60000]
+            if not ks:
+                act = 7
+            else:
+                blks = []
+                for k in ks:
+                    n = int(min(rng.integers(1, 50000), caps[k].size // 2 - at[k], 60000 - since[k]))
+                    blks.append(caps[k][2 * at[k]: 2 * (at[k] + n)]); at[k] += n; since[k] += n
+                if len(ks) == 1 and rng.integers(0, 2):
+                    d.push(ks[0], blks[0])
+                else:
+                    d.push_batch(ks, blks)
+        if act in (6, 7):
+            d.process()
+            since = [0] * S
+        elif act >= 8:
+            pop(int(rng.integers(0, S)))
+    for k in range(S):
+        d.flush(k)
+    d.process()
+    for k in range(S):
+        pop(k)
+        exp = oracle.receive(caps[k], streaming=True)
+        fr = np.concatenate(frames[k]); meta = np.concatenate(metas[k])
+        assert np.array_equal(fr, exp["frames"]), (seed, k)
+        assert np.array_equal(meta["viterbi_metric"], exp["metrics"]) and np.array_equal(meta["release_symbol"], exp["frame_sym"]), (seed, k)
+        events_match(amd, np.concatenate(events[k]), exp["events"])
+        assert d.state(k).total_symbols == exp["n_soft"]
+    d.close()
