@@ -972,3 +972,32 @@ def test_random_call_sequences(amd, oracle, iq10, seed):
         events_match(amd, np.concatenate(events[k]), exp["events"])
         assert d.state(k).total_symbols == exp["n_soft"]
     d.close()
+
+
+def test_contexts_in_concurrent_host_threads(amd, oracle, iq10):
+    """'A ctx is not thread-safe, distinct ctxs are independent' (include/opv_demod.h): four host threads, one
+    context each, running at the same time (ctypes drops the GIL in the calls)."""
+    import threading
+    caps = [impair(iq10, amp=2000.0 + 500 * k, f0_hz=-900.0 + 600 * k, ebn0_db=16.0, seed=60 + k) for k in range(4)]
+    exps = [oracle.receive(x, streaming=True) for x in caps]
+    out = [None] * 4
+
+    def work(k):
+        try:
+            for rep in range(3):
+                d = amd.Demod(2, max_samples=iq10.size // 2 + 64, streaming=True)
+                d.set_frontend(4 if k == 3 else 1)
+                out[k] = d.receive([caps[k], caps[(k + 1) % 4]])
+                d.close()
+        except Exception as e:           # surfaces in the main thread below
+            out[k] = e
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for k in range(4):
+        assert not isinstance(out[k], Exception), out[k]
+        check_stream(amd, out[k][0], exps[k], f"thread {k} stream 0")
+        check_stream(amd, out[k][1], exps[(k + 1) % 4], f"thread {k} stream 1")
