@@ -1001,3 +1001,34 @@ def test_contexts_in_concurrent_host_threads(amd, oracle, iq10):
         assert not isinstance(out[k], Exception), out[k]
         check_stream(amd, out[k][0], exps[k], f"thread {k} stream 0")
         check_stream(amd, out[k][1], exps[(k + 1) % 4], f"thread {k} stream 1")
+
+
+def test_host_cli_irregular_pipe_writes(amd, golden, iq10):
+    """stdin delivered in pieces that split samples (1, 3, 5, 4097, 65537 ... bytes) and with a trailing partial
+    sample: the reader carries the split sample over (reference :1022 reads 4 bytes at a time) and ignores the
+    incomplete one at EOF; output identical to the one-shot run."""
+    import subprocess
+    import threading
+    arrays, _ = golden
+    exe = str(ROOT / "opv-cxx-demod_amd" / "bin" / "opv-demod")
+    raw = iq10.tobytes() + b"\x12\x34\x56"           # 3 stray bytes: an incomplete last sample
+    rng = np.random.default_rng(8)
+    for args, key in ((["-s", "-r", "-q"], "c1_stream_frames"), (["-r", "-q"], "c1_batch_frames")):
+        p = subprocess.Popen([exe] + args, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+
+        def feed():
+            pos = 0
+            sizes = [1, 3, 5, 2, 4097, 65537, 7, 1048579, 13]
+            i = 0
+            while pos < len(raw):
+                n = sizes[i % len(sizes)] if i < 40 else int(rng.integers(1, 300000))
+                p.stdin.write(raw[pos: pos + n]); p.stdin.flush()
+                pos += n; i += 1
+            p.stdin.close()
+
+        t = threading.Thread(target=feed)
+        t.start()
+        out = p.stdout.read()
+        t.join()
+        assert p.wait(timeout=120) == 0
+        assert out == arrays[key].tobytes(), args
