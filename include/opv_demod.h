@@ -52,8 +52,8 @@ enum {
 };
 
 /* Replaces the flag parsing of main() (src/opv-demod.cpp:944-974) for the flags that reach
- * the hot path: -s, -o <hz>, -a <alpha>. (-c/-p select the coherent demodulator, which is
- * out of scope; -q/-r only affect host printing.) */
+ * the hot path: -s, -o <hz>, -a <alpha>. (-c/-p select the batch coherent demodulator, which has no
+ * reproducible output to build to - DESIGN.md §7; -q/-r only affect host printing.) */
 typedef struct opv_cfg {
     int32_t streaming;        /* 1: -s chunked semantics (:995-1125); 0: batch (:1132-1216) */
     int32_t have_init_offset; /* -o given: skip the offset search in streaming mode (:1004,:1031) */
