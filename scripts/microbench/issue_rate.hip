@@ -23,7 +23,11 @@ __global__ __launch_bounds__(64) void k_chain(int n, double* out) {
             if (KIND == 5) a = pad[(__double2loint(a) & 1023) + 64];                              // dependent LDS read (b64)
             if (KIND == 6) a = __builtin_amdgcn_rcp(a) + c;                                       // v_rcp_f64 + add
             if (KIND == 7) { a = fma(a, b, c); a2 = fma(a2, b, c); a3 = fma(a3, b, c); a4 = fma(a4, b, c); }  // 4 independent chains
+            if (KIND == 8 || KIND == 9) { a = fma(a, b, c); a2 = fma(a2, b, c); a3 = fma(a3, b, c); a4 = fma(a4, b, c); }
         }
+        // one store per 64 FMAs: KIND 8 all lanes to the SAME address (the front-end's soft-log store), KIND 9 lane 0 only
+        if (KIND == 8) out[8192 + blockIdx.x * 4096 + (i & 4095)] = a;
+        if (KIND == 9 && threadIdx.x == 0) out[8192 + blockIdx.x * 4096 + (i & 4095)] = a;
     }
     if (threadIdx.x == 0) out[blockIdx.x] = a + lo + hi + a2 + a3 + a4;
 }
@@ -50,7 +54,7 @@ void run(const char* name, double* d) {
 
 int main() {
     double* d;
-    hipMalloc(&d, 8192 * 8);
+    hipMalloc(&d, (8192 + 2048 * 4096) * 8);
     run<0>("v_fma_f64 (dependent)", d);
     run<1>("v_mov_dpp row_ror + v_add", d);
     run<2>("v_permlane32_swap", d);
@@ -59,5 +63,7 @@ int main() {
     run<5>("ds_read_b64 (dependent address)", d);
     run<6>("v_rcp_f64 + v_add_f64", d);
     run<7>("4 independent v_fma_f64 (per 4)", d);
+    run<8>("same + 64-lane same-address store", d);
+    run<9>("same + one-lane store", d);
     return 0;
 }
