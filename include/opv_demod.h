@@ -177,6 +177,12 @@ long opv_tap_chunks(opv_ctx* ctx, int stream, uint32_t first_chunk, double* out5
 /* 134 candidate energies of the offset search in scan order (121 coarse, 13 fine) */
 int opv_tap_offset_energies(opv_ctx* ctx, int stream, double* out134);
 
+/* Where and how fast the wavefront that served `stream` ran in the LAST front-end launch (one wave per stream
+ * mapping only): out[0] = HW_REG_HW_ID, out[1] = HW_REG_XCC_ID, out[2] = shader-clock cycles (s_memtime) and
+ * out[3] = 100 MHz ticks (s_memrealtime) spent inside the kernel. Diagnostic: placement census and the clock the
+ * chip held (cycles / ticks x 100 MHz); no counterpart in the reference. */
+int opv_tap_wave_info(opv_ctx* ctx, int stream, uint64_t out[4]);
+
 /* Stand-alone FrameDecoder::decode (src/opv-demod.cpp:854-898) on n_frames payloads of
  * 2144 host doubles each. Optional taps: q (quantised, :862-866), deint (:869-871),
  * bits (Viterbi hard decisions, :874-875). metrics[i] = path metric or -1. */

@@ -205,6 +205,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                                                                  OpvGlobalCfg cfg) {
     OpvStream& st = streams[blockIdx.x];
     const int lane = threadIdx.x;
+    const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 
     __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
     const unsigned char* ringb = lds;
@@ -668,5 +669,12 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
         st.fo_sum = fo_sum;
         st.origin = origin; st.n_soft = n_soft; st.total_samples = total_samples;
         st.n_chunks = n_chunks; st.tail_done = tail_done; st.overflow = overflow;
+        // where and at which clock this stream's wave ran (two scalar reads per launch; opv_tap_wave_info)
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        st.dbg_hw_id = hw; st.dbg_xcc_id = xcc;
+        st.dbg_cycles = __builtin_amdgcn_s_memtime() - dbg_t0;
+        st.dbg_ticks = __builtin_amdgcn_s_memrealtime() - dbg_r0;
     }
 }

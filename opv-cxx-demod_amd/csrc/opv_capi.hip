@@ -665,6 +665,15 @@ extern "C" int opv_tap_offset_energies(opv_ctx* c, int s, double* out134) {
     return OPV_OK;
 }
 
+extern "C" int opv_tap_wave_info(opv_ctx* c, int s, uint64_t out[4]) {
+    if (int r = check_stream(c, s)) return r;
+    if (!out) return fail(OPV_EINVAL, "null out");
+    if (int r = c->refresh()) return r;
+    const OpvStream& st = c->mirror[s];
+    out[0] = st.dbg_hw_id; out[1] = st.dbg_xcc_id; out[2] = st.dbg_cycles; out[3] = st.dbg_ticks;
+    return OPV_OK;
+}
+
 extern "C" int opv_decode_payloads(opv_ctx* c, const double* soft, size_t n, uint8_t* out, int32_t* metrics,
                                    int8_t* q, int8_t* deint, uint8_t* bits) {
     if (!c || !soft || !out || !metrics) return fail(OPV_EINVAL, "null argument");

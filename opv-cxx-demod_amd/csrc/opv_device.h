@@ -82,6 +82,10 @@ struct OpvStream {
     uint32_t n_frames;        // frames released (total_frames_)
     uint32_t n_events;
     uint32_t dec_from;        // first frame record k_frame_decode must handle this round
+
+    // ---- diagnostics of the last front-end launch (opv_tap_wave_info) ----
+    uint32_t dbg_hw_id, dbg_xcc_id;   // HW_REG_HW_ID / HW_REG_XCC_ID of the wave that served the stream
+    uint64_t dbg_cycles, dbg_ticks;   // s_memtime (shader clock) and s_memrealtime (100 MHz) spent in the kernel
 };
 
 struct OpvGlobalCfg {

@@ -31,7 +31,7 @@ EXPORTS = [
     "opv_create", "opv_destroy", "opv_last_error", "opv_abi_version", "opv_push_iq", "opv_push_iq_batch", "opv_flush",
     "opv_attach_device_iq", "opv_process", "opv_sync", "opv_set_frontend", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_tap_soft", "opv_tap_chunks",
-    "opv_tap_offset_energies", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_modulated_samples",
+    "opv_tap_offset_energies", "opv_tap_wave_info", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_modulated_samples",
     "opv_tx_modulate", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device",
 ]
 
@@ -115,6 +115,7 @@ def lib():
         L.opv_tap_chunks.restype = C.c_long
         L.opv_tap_chunks.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
         L.opv_tap_offset_energies.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.opv_tap_wave_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.opv_decode_payloads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
         L.opv_tx_bert_frame.restype = None
@@ -258,6 +259,12 @@ class Demod:
         out = np.zeros(134, np.float64)
         _chk(lib().opv_tap_offset_energies(self.h, stream, out.ctypes.data))
         return out
+
+    def wave_info(self, stream):
+        """(HW_ID, XCC_ID, shader cycles, 100 MHz ticks) of the wave that ran the stream's last front-end launch"""
+        out = (C.c_uint64 * 4)()
+        _chk(lib().opv_tap_wave_info(self.h, stream, out))
+        return tuple(int(v) for v in out)
 
     def decode_payloads(self, soft, taps=False):
         soft = np.ascontiguousarray(soft, np.float64).reshape(-1, ENCODED_BITS)
