@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the MI355X-native OPV MSK receive chain (demod + Viterbi).
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1: launched through
-torch.distributed.run, one rank per GPU). Rank 0 prints ONE JSON line.
+Contract (driver):  python bench.py --gpus N --steps K --warmup W. One rank per GPU: under
+torch.distributed.run the ranks come from the launcher (RANK / LOCAL_RANK / WORLD_SIZE); from a bare shell
+`python bench.py --gpus N` starts its N ranks itself (child processes, before anything touches a GPU) and
+relays rank 0's line. Rank 0 prints ONE JSON line.
 
 Workload. A "step" is one pass of the whole hot path (offset search -> MSK front-end -> sync
 tracker -> frame decode) over one batch of synthetic captures that are ALREADY RESIDENT IN HBM.
@@ -31,23 +33,39 @@ from pathlib import Path
 import numpy as np
 
 ROOT = Path(__file__).resolve().parent
-sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT))
 
 FRAME_SAMPLES = 86720
 ALGO_BYTES_PER_SAMPLE = 4.0 + 134.0 / FRAME_SAMPLES  # 4 B in + 134 B / frame out
 HBM_PEAK_GBS = 8000.0                                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-class DevPtr:
-    """Zero-copy torch view of library-owned device memory (CUDA array interface v2)."""
-
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"data": (ptr, False), "shape": shape, "typestr": typestr, "version": 2}
-
-
 def load_amd():
-    from amd_lib import load
-    return load()
+    from __graft_entry__ import load_opv_amd
+    return load_opv_amd()
+
+
+def load_pkg(name):
+    from __graft_entry__ import load_pkg_module
+    return load_pkg_module(name)
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as child processes (this parent never
+    touches a GPU, and nothing is exec'ed from a process that has), wait, exit with the worst status."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OPV_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
 
 
 def cpu_baseline(iq_bytes, n_samples):
@@ -62,6 +80,7 @@ def cpu_baseline(iq_bytes, n_samples):
         return {"value": n_samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "reference",
                 "sample": f"oracle/_ref/opv-demod -s -r -q on the clean {n_samples // FRAME_SAMPLES}-frame "
                           f"capture via a pipe ({dt:.2f} s, {nf} frames out)"}
+    sys.path.insert(0, str(ROOT / "tests"))       # the oracle binding is test infrastructure; only this leg uses it
     from oracle_lib import Oracle
     o = Oracle()
     iq = np.frombuffer(iq_bytes, np.int16)
@@ -117,16 +136,21 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip configs[1], the sweep and the CPU baseline")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus, sys.argv[1:])              # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} disagrees with WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
@@ -142,38 +166,25 @@ def main():
 
     amd = load_amd()
     amd.lib()
+    sharding, workload = load_pkg("sharding"), load_pkg("workload")
+    DevPtr = workload.DevPtr
     S, F = args.streams, args.frames
 
     # ---- synthetic input, generated IN HBM: device modulator (bit-identical to `opv-mod`, see
-    # tests) -> device channel tool. Every stream carries its own BERT payload sequence.
+    # tests) -> device channel tool. Every stream carries its own BERT payload sequence. Rank r owns the
+    # contiguous shard [r S, (r + 1) S) of the world * S global streams (sharding.stream_range).
+    mine = sharding.stream_range(rank, world, world * S)
     n = amd.lib().opv_tx_modulated_samples(F)
-    assert n % 4 == 0
-    d_clean = torch.empty(2 * n, dtype=torch.int16, device=dev)
-    d_iq = torch.empty((S, 2 * n), dtype=torch.int16, device=dev)
     dm = amd.Demod(S, max_samples=n + 64, streaming=True, device=local_rank)
-    amp = 2000.0
-    sigma = 0.0
-    if args.ebn0 > 0:
-        sigma = float(np.sqrt(80.0 * amp * amp / 10.0 ** (args.ebn0 / 10.0) / 2.0))
-    tx_all = np.empty((S, F, 134), np.uint8)
-    t_mod = 0.0
-    for k in range(S):
-        gk = rank * S + k
-        tx_all[k] = amd.bert_frames(F, callsign=f"S{gk}", first=1000 * gk)
-        t0 = time.perf_counter()
-        dm.modulate_device(tx_all[k], d_clean.data_ptr())
-        t_mod += time.perf_counter() - t0
-        f0 = -1500.0 + 3000.0 * (gk % 64) / 63.0
-        dm.channel(d_clean.data_ptr(), d_iq[k].data_ptr(), n, gain=amp / 16383.0, f0_hz=f0, sigma=sigma,
-                   seed=1000 + gk)
-    dm.sync()
+    t0 = time.perf_counter()
+    d_iq, tx_all, n = workload.generate(amd, dm, torch, dev, mine, F, args.ebn0)
     torch.cuda.synchronize()
+    t_mod = time.perf_counter() - t0
     tx_frames = amd.bert_frames(F)                       # configs[1] / CPU-baseline capture (W5NYV)
 
-    fptr, mptr, cptr, fcap = dm.device_frames()
-    frames_view = torch.as_tensor(DevPtr(fptr, (S, fcap, 134), "|u1"), device=dev)
-    counts_view = torch.as_tensor(DevPtr(cptr, (S,), "<i4"), device=dev)
-    gathered = [torch.empty_like(frames_view) for _ in range(world)] if (use_dist and rank == 0) else None
+    frames_view, counts_view = workload.frame_views(dm, torch, dev)
+    fcap = frames_view.shape[1]
+    gathered = {}
     expect = torch.from_numpy(tx_all).to(dev)
 
     stats = {}
@@ -184,8 +195,8 @@ def main():
             dm.attach(k, d_iq[k].data_ptr(), n, eof=True)
         dm.process()
         dm.sync()
-        if use_dist:
-            dist.gather(frames_view, gathered, dst=0)    # RCCL over xGMI: frames back to rank 0
+        if use_dist:                                     # RCCL over xGMI: frames + counts back to rank 0
+            gathered["frames"], gathered["counts"] = sharding.gather_frames(frames_view, counts_view, dst=0)
         if check:
             # full-size round trip: every stream must release exactly F frames, in order, and
             # (at 16 dB a handful of frames carry residual channel errors) >= 99% of them must
@@ -225,10 +236,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         if rank == 0:
-            g = torch.stack(gathered)                    # [world, S, fcap, 134] in global stream order
+            g = gathered["frames"]                       # [world, S, fcap, 134] in global stream order
             assert bool((g[0] == frames_view).all().item()), "gathered frames of rank 0 differ from the local ones"
-            exp_all = np.stack([np.stack([amd.bert_frames(F, callsign=f"S{r * S + k}", first=1000 * (r * S + k))
-                                          for k in range(S)]) for r in range(world)])
+            assert bool((gathered["counts"] == F).all().item()), "a gathered stream released a wrong number of frames"
+            exp_all = np.stack([np.stack([workload.tx_frames(amd, gk, F) for gk in sharding.stream_range(r, world, world * S)])
+                                for r in range(world)])
             same = (g[:, :, :F, :].cpu().numpy() == exp_all).all(axis=3)
             stats["gathered_frames_total"] = int(same.size)
             stats["gathered_frames_exact"] = int(same.sum())
@@ -244,12 +256,26 @@ def main():
     # profile itself); they are only attached when this run is the profiled configuration.
     traffic = None
     traffic_note = "no PMC passes recorded for this configuration (see profiles/collect.sh)"
+    issue = None
     try:
-        tj = json.loads((ROOT / "profiles" / "r01_traffic.json").read_text())
+        tj = json.loads(sorted((ROOT / "profiles").glob("r[0-9][0-9]_traffic.json"))[-1].read_text())
         w = tj["workload"]
         if (w["streams_per_gpu"], w["frames_per_stream"], w["ebn0"]) == (S, F, args.ebn0):
             traffic = round(tj["hbm_bytes_per_launch"] / (fe_ms * 1e-3) / 1e9, 3)
             traffic_note = tj["source"] + "; " + tj["correction"]
+        # The view that actually bounds this kernel: wave-instructions issued vs the issue slots of
+        # the chip (1024 SIMDs, one fp64 wave-instruction per 4 cycles each, at the 2.4 GHz the kernel holds -
+        # opv_tap_wave_info). instr_per_symbol comes from the SQ_INSTS_* passes of the same workload.
+        ips = tj.get("instr_per_symbol")
+        if ips:
+            per_sym = float(sum(ips.values()))
+            n_sym = launch_samples / 40.0
+            slots = 1024 * (fe_ms * 1e-3) * 2.4e9 / 4.0
+            issue = {"instr_per_symbol": ips, "wave_cycles_per_symbol": tj.get("wave_cycles_per_symbol"),
+                     "chip_issue_frac": round(per_sym * n_sym / slots, 4),
+                     "wave_issue_frac": round(per_sym * 4.0 / tj["wave_cycles_per_symbol"], 3) if tj.get("wave_cycles_per_symbol") else None,
+                     "note": "chip_issue_frac: issued wave-instructions / (1024 SIMDs x kernel cycles / 4); "
+                             "wave_issue_frac: the same for the SIMDs that carry a stream (one wave each)"}
     except Exception:
         pass
 
@@ -269,12 +295,16 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_msk_frontend", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "traffic_note": traffic_note,
+                     "issue": issue,
                      "kernel_ms": round(fe_ms, 3),
                      "note": "issue/latency-bound per-symbol feedback recurrence at 64 waves per GPU, not bandwidth "
                              "(DESIGN.md); extras.stream_sweep shows the same kernel with the chip filled"},
         "kernel_ms": {k: round(float(np.mean([x[k] for x in kt])), 3) for k in kt[0]},
         "check": stats,
     }
+    # what a timed step spends outside the four kernels: opv_reset_stream (two stream syncs, a 90 KB upload, a
+    # metrics fill), 64 opv_attach calls, the launches, and the frame gather when N > 1
+    out["non_kernel_ms_per_step"] = round(out["ms_per_step"] - sum(out["kernel_ms"].values()), 3)
 
     if rank == 0 and not args.no_extras and world == 1:
         extras = {}
@@ -395,6 +425,9 @@ def main():
                                     "process_ms": med(2), "pop_ms": med(3), "frames_per_round": int(rounds[-1][4])}
             lv.close()
             del host, host_np
+        tgt = [int(k.split("x")[0]) for k, v in sweep.items() if v.get("1_per_wave", {}).get("Msamples/s", 0) >= 21680.0]
+        extras["streams_for_target"] = {"target_Msamples/s": 21680.0, "smallest_swept_stream_count_meeting_it": min(tgt) if tgt else None,
+                                        "swept": sorted(int(k.split("x")[0]) for k in sweep)}
         out["extras"] = extras
         base = d_base.cpu().numpy()
         raw = base.tobytes()
@@ -403,8 +436,13 @@ def main():
         out["setup"] = {"device_modulate_s_all_streams": round(t_mod, 2),
                         "device_modulate_one_stream": {"s": round(t_dev_mod, 3), "Msamples/s": round(n / t_dev_mod / 1e6, 1),
                                                         "note": "opv_tx_modulate_device incl. host bit-level pass + H2D of codes"}}
-    elif rank == 0:
+    elif rank == 0 and args.no_extras:
         out["cpu_baseline"] = None
+    elif rank == 0:
+        # N > 1: the same bounded CPU sample as the N = 1 line, timed on rank 0's host cores while
+        # the other ranks wait at the end of the job (outside the timed region)
+        raw = np.ascontiguousarray(amd.modulate(tx_frames)).tobytes()
+        out["cpu_baseline"] = cpu_baseline(raw, n)
 
     dm.close()
     if rank == 0:

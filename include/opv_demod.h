@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define OPV_ABI_VERSION 1
+#define OPV_ABI_VERSION 2
 
 #define OPV_SAMPLES_PER_SYMBOL 40    /* src/opv-demod.cpp:39  */
 #define OPV_FRAME_BYTES 134          /* :49  */
@@ -34,7 +34,8 @@ enum {
     OPV_EINVAL = -1,   /* bad argument                                   */
     OPV_ENODEV = -2,   /* no usable HIP device / kernels failed to load  */
     OPV_ENOMEM = -3,   /* device or host allocation failed               */
-    OPV_ECAPACITY = -4,/* per-stream capacity (opv_cfg.max_samples) exceeded */
+    OPV_ECAPACITY = -4,/* per-stream capacity (opv_cfg.max_samples) exceeded: unprocessed samples + a push do not fit
+                          (frames waiting to be popped hold their stream back; pop them and push again) */
     OPV_EHIP = -5,     /* a HIP runtime call failed (see opv_last_error) */
     OPV_ESTATE = -6    /* call not valid in this state (e.g. push after flush) */
 };
@@ -60,7 +61,9 @@ typedef struct opv_cfg {
     double init_offset_hz;    /* -o value */
     double afc_alpha;         /* -a value; 0.001 if <= 0 is NOT substituted: pass 0.001 for the default (:945) */
     int32_t device;           /* HIP device ordinal */
-    int32_t keep_soft;        /* reserved (soft symbols are always retained in this version) */
+    int32_t reserved0;        /* ignored (was keep_soft in ABI 1): the soft-symbol log is the hand-over between the
+                                 front-end kernel and the tracker / frame decoder kernels, so it is always written
+                                 (8 B per symbol = 5 % on top of the 4 B per sample read) */
     uint64_t max_samples;     /* per-stream DEVICE BUFFER capacity in IQ samples (< 2^31). Pushed streams may be
                                  arbitrarily long: consumed samples / soft symbols are dropped when the buffer
                                  fills (>= ~3 chunks + the largest push is enough); an attached capture must fit */
@@ -70,7 +73,8 @@ typedef struct opv_cfg {
  * (src/opv-demod.cpp:1048-1062: metric, res.sync_quality, sym index of release). */
 typedef struct opv_frame_meta {
     int32_t viterbi_metric;   /* ViterbiDecoder::decode return (:845); 0 == "perfect" (:910) */
-    int32_t reserved;
+    int32_t sync_ok;          /* 1: the sync word in front of this payload passed its check (HUNTING hit :642, or
+                                 LOCKED corr >= 0.70 :688); 0: flywheel frame released after a sync MISS (:709-712) */
     double sync_quality;      /* SyncTracker::Result::sync_quality (:611) */
     uint64_t release_symbol;  /* global symbol index at which the frame was released (:1046) */
     uint64_t payload_symbol;  /* global symbol index of the first payload symbol */
@@ -99,6 +103,14 @@ typedef struct opv_stream_state {
     int32_t frames_perfect;   /* metric == 0 (`perfect`, :1054) */
     int32_t n_chunks;         /* demodulate() calls made */
     int32_t flushed;
+    uint32_t events_dropped;  /* tracker events overwritten before opv_pop_events read them (the event log is lossy) */
+    uint32_t edge_ties;       /* symbols whose tone choice the reference decides by the rounding of its own LO: a window
+                                 with exactly one non-zero tap next to digital silence. Each may move the AFC by one
+                                 step (<= 27 Hz, decaying) away from the reference; 0 on any capture without exact zeros */
+    int32_t stalled;          /* back-pressure after the last opv_process: bit 0 = soft-symbol ring full, bit 1 = ring of
+                                 unpopped frames full. The stream resumes at the next opv_process after opv_pop_frames */
+    int32_t offset_ties;      /* offset-search candidates that were within 1e-11 (relative energy) of the winner and were
+                                 therefore re-evaluated in the reference's own order of operations (estimate_offset :143-159) */
 } opv_stream_state;
 
 typedef struct opv_ctx opv_ctx;
@@ -156,7 +168,13 @@ int opv_kernel_times(opv_ctx* ctx, float ms_out[4]);
  * opv_pop_frames replaces the frame writer (src/opv-demod.cpp:1052-1062): frames whose
  * decoder returned -1 (silent frame, :859) are skipped exactly as the reference skips
  * them. Copies up to cap_frames not-yet-popped frames (134 B each, in release order) and
- * their meta; returns the number copied or a negative error. Implies opv_sync. */
+ * their meta; returns the number copied or a negative error. Implies opv_sync.
+ * Frames are never dropped: a stream whose ring of unpopped frames is full pauses (opv_stream_state.stalled)
+ * and resumes at the next opv_process after a pop.
+ * opv_pop_events returns the tracker lines the reference prints to stderr (:651,677,695,699,705). Reading them
+ * is OPTIONAL (opv-modem discards the child's stderr): the log is a ring of the most recent entries per stream
+ * (4 per frame of capacity + 64); lines not read in time are overwritten and counted in
+ * opv_stream_state.events_dropped, nothing else is affected. */
 long opv_pop_frames(opv_ctx* ctx, int stream, uint8_t* out134, size_t cap_frames, opv_frame_meta* meta);
 long opv_pop_events(opv_ctx* ctx, int stream, opv_event* out, size_t cap_events);
 int opv_get_state(opv_ctx* ctx, int stream, opv_stream_state* out);

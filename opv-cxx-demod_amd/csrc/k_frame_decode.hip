@@ -219,11 +219,12 @@ static_assert(2 * OPV_CODED % 8 == 0 && 2 * OPV_CODED + 8 * OPV_FBITS <= 17152, 
 
 }  // namespace
 
-// grid = (max new frames per stream, n_streams); frames dec_from .. n_frames-1 of each stream
-extern "C" __global__ __launch_bounds__(64) void k_frame_decode(OpvStream* __restrict__ streams) {
+// grid = n_streams x (max new frames per stream), flattened (stream-major: a stream's frames are neighbours, so are
+// their soft symbols in L2); frames dec_from .. n_frames-1 of each stream
+extern "C" __global__ __launch_bounds__(64) void k_frame_decode(OpvStream* __restrict__ streams, uint32_t per_stream) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kDecodeLds];
-    OpvStream& st = streams[blockIdx.y];
-    const uint32_t f = st.dec_from + blockIdx.x;
+    OpvStream& st = streams[blockIdx.x / per_stream];
+    const uint32_t f = st.dec_from + blockIdx.x % per_stream;
     if (f >= st.n_frames) return;
     const uint32_t slot = f % st.cap_frames;  // frame records / frames / metrics are rings
     const OpvFrameRec rec = st.frec[slot];

@@ -83,7 +83,7 @@ static_assert((kRing & (kRing - 1)) == 0, "ring must be a power of two");
 // LDS map (bytes): ring | guard | atan table (33 rows x 10 doubles: c0..c8, pad)
 constexpr uint32_t kTabOff = kRingBytes + kGuardBytes;   // 16400
 constexpr uint32_t kTabRow = 10;
-constexpr uint32_t kLdsBytes = kTabOff + 33 * kTabRow * 8;  // 19040 <= 20480: eight workgroups per CU
+// LDS per workgroup: WPB x kTabOff + the atan table = 19 040 B for one wave (eight workgroups per CU), 68 240 B for four (two)
 static_assert(kTabOff % 16 == 0, "16-byte LDS alignment");
 
 typedef __attribute__((address_space(1))) double gdouble;
@@ -172,10 +172,25 @@ __device__ inline void expj_small(double kfs, double fo, const SinCosK& k, doubl
 // E_t(k) = exp(j(-/+ k pi/2 + (80 pi/Fs) sum_{j<k} fo_j)), rebuilt here from the running sum of fo
 // (fo_sum: over the symbols BEFORE this one; ksym: their number). Checked on 598 gap edges by
 // tests/test_gpu_parity.py::test_many_silence_gaps_signed_zero_rule.
-__device__ __noinline__ double silence_pd(double dr, double di, PrevSums prv, bool dom1, double fo_sum, uint64_t ksym) {
+//
+// The one input class that is NOT reproducible is counted here (`ties`, reported as
+// opv_stream_state.edge_ties): a window with exactly ONE non-zero tap, i.e. the first symbol a burst
+// touches or the last one it leaves. Both tone energies are then |s|^2 in exact arithmetic (P1 P2 ==
+// P3 P4, soft = 4 (P3 P4 - P1 P2) = 0) and the reference's e1 > e2 (ref :272/:291) is decided by the
+// rounding of its own cos^2 + sin^2 at the accumulated LO phase, which this kernel does not carry. Such a
+// symbol always has digital silence on one side, so it passes through this routine either as `cur`
+// (leading edge: prev is zero) or as `prv` (trailing edge: dom is zero) - no cost on the symbol path.
+__device__ inline bool tone_tie(double p1, double p2, double p3, double p4) {
+    const double x = p1 * p2, y = p3 * p4;
+    return (p1 != 0.0 || p2 != 0.0 || p3 != 0.0 || p4 != 0.0) && fabs(y - x) <= 1e-12 * (fabs(x) + fabs(y));
+}
+// Returns {pd, 1.0 if such a tie was seen else 0.0} (by value: no stack slot on the caller's side).
+__device__ __noinline__ double2 silence_pd(double dr, double di, PrevSums prv, bool dom1, double fo_sum, uint64_t ksym,
+                                           double c1, double c2, double c3, double c4) {
     const double pr = dom1 ? prv.a + prv.b : prv.a - prv.b, pi = dom1 ? prv.c - prv.d : prv.c + prv.d;
     const bool dom_zero = (dr == 0.0 && di == 0.0), prev_zero = (pr == 0.0 && pi == 0.0);
-    if (dom_zero == prev_zero) return 0.0;
+    if (dom_zero == prev_zero) return make_double2(0.0, 0.0);
+    const double tie = (prev_zero ? tone_tie(c1, c2, c3, c4) : tone_tie(prv.a, prv.b, prv.c, prv.d)) ? 1.0 : 0.0;
     double th = (80.0 * kPi / kFs) * fo_sum;
     th -= kTwoPi * rint(th / kTwoPi);
     double sn, cs;
@@ -194,23 +209,35 @@ __device__ __noinline__ double silence_pd(double dr, double di, PrevSums prv, bo
     }
     const double qr = vr * er2 + vi * ei2;          // v * conj(E)
     const double qi = vi * er2 - vr * ei2;
-    return (qr < 0.0 && qi < 0.0) ? kPi : 0.0;
+    return make_double2((qr < 0.0 && qi < 0.0) ? kPi : 0.0, tie);
 }
 
 }  // namespace
 
 #include "opv_atan2.h"  // kOpvAtanTab (constant-memory image of the table) + host reference routine
 
-extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __restrict__ streams,
-                                                                 OpvGlobalCfg cfg) {
-    OpvStream& st = streams[blockIdx.x];
-    const int lane = threadIdx.x;
+// WPB = wavefronts (= streams) per workgroup. One wave per workgroup is the natural shape, but the dispatcher
+// places single-wave workgroups without regard to SIMDs: with 1024 of them on the chip's 1024 SIMDs, 88 SIMDs
+// received two waves and 88 none (census from this kernel's own HW_ID tap, profiles/r02_placement_1024_streams.txt),
+// and the doubled-up waves - this kernel keeps a SIMD's fp64 pipe 80 % busy on its own - took 1.74x as long and set
+// the kernel's duration. A 256-thread workgroup's four waves always land on the four SIMDs of one CU, so from 513
+// streams on the shim launches four streams per workgroup (k_msk_frontend_wg4). Waves of a workgroup share nothing
+// but the atan table.
+template <int WPB>
+__device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ streams, OpvGlobalCfg cfg, int n_streams) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sidx = (int)blockIdx.x * WPB + wave;
     const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[WPB * kTabOff + 33 * kTabRow * 8];
+    unsigned char* const lds = lds_all + wave * kTabOff;      // this wave's ring + guard
     const unsigned char* ringb = lds;
-    double* atab = reinterpret_cast<double*>(lds + kTabOff);
-    for (int i = lane; i < 33 * (int)kTabRow; i += 64) atab[i] = (&kOpvAtanTab[0][0])[i];
+    double* atab = reinterpret_cast<double*>(lds_all + WPB * kTabOff);
+    for (int i = threadIdx.x; i < 33 * (int)kTabRow; i += 64 * WPB) atab[i] = (&kOpvAtanTab[0][0])[i];
+    __syncthreads();                     // atan table visible to every wave of the workgroup
+    if (sidx >= n_streams) return;       // a last, partly filled workgroup
+    OpvStream& st = streams[sidx];
 
     // ---- per-lane constants -------------------------------------------------------------
     const double kf = (double)(lane - 10);
@@ -252,7 +279,8 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
     uint32_t n_chunks = uni(st.n_chunks);
     int tail_done = (int)uni((uint32_t)st.tail_done);
     const int eof = (int)uni((uint32_t)st.eof);
-    int overflow = (int)uni((uint32_t)st.overflow);
+    int overflow = (int)uni((uint32_t)st.overflow), stalled = 0;
+    uint32_t edge_ties = uni(st.edge_ties);
     const uint64_t cap_soft = st.cap_soft;
     if (cap_soft > (1ull << 28)) overflow = 1;  // byte offsets into the soft ring are kept in 32 bits
     // oldest soft symbol the tracker may still read: its 24-symbol window, or the payload / next
@@ -308,7 +336,6 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): both tiles (and the guard) landed
     bool evt_issue = true;               // next tile event: request tile t_lo+2 (else: wait for the newest)
     uint32_t next_evt = (t_lo + 1u) * kTile + kBack;
-    __syncthreads();                     // atan table visible (single wave: LDS ordering only)
 
     for (;;) {
         // ---- which demodulate() call comes next (ref :1026 / :1088 / :1173) ----------------
@@ -324,8 +351,10 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
             N = n_avail;
             last = true;
         }
-        // worst case one symbol per 38 samples: refuse the call rather than overrun the soft log
-        if (overflow || (n_soft - soft_keep) + (uint64_t)(N / 38u + 2u) > cap_soft) { overflow = 1; break; }
+        // worst case one symbol per 38 samples: postpone the call rather than overrun soft symbols the tracker
+        // still needs (back-pressure: it is retried next round, once frames have been popped)
+        if (overflow) break;
+        if ((n_soft - soft_keep) + (uint64_t)(N / 38u + 2u) > cap_soft) { stalled = 1; break; }
 
         const double Nd = (double)N;
         double pos = mu;                                   // ref :217
@@ -606,8 +635,12 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
                 pd = fma(sx, pd, pd_off);
                 pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));  // sign of cy
 
-                if (__builtin_expect(uni_eq(mx, 0.0), 0))           // digital silence on either side
-                    pd = silence_pd(dr, di, prv, soft < 0.0, fo_sum, n_soft + (((my_soft_off - soft_off0) & soft_bmask) >> 3));
+                if (__builtin_expect(uni_eq(mx, 0.0), 0)) {         // digital silence on either side
+                    const double2 sp = silence_pd(dr, di, prv, soft < 0.0, fo_sum, n_soft + (((my_soft_off - soft_off0) & soft_bmask) >> 3),
+                                                  P1o, P2o, P3o, P4o);
+                    pd = sp.x;
+                    edge_ties += uni((uint32_t)sp.y);
+                }
             }
             if constexpr (!kFirst) {                                // ref :300-303
                 // (written as instructions: through fmin/fmax hipcc re-canonicalises the two loop-invariant
@@ -669,6 +702,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
         st.fo_sum = fo_sum;
         st.origin = origin; st.n_soft = n_soft; st.total_samples = total_samples;
         st.n_chunks = n_chunks; st.tail_done = tail_done; st.overflow = overflow;
+        st.stalled = stalled; st.edge_ties = edge_ties;
         // where and at which clock this stream's wave ran (two scalar reads per launch; opv_tap_wave_info)
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -677,4 +711,14 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __res
         st.dbg_cycles = __builtin_amdgcn_s_memtime() - dbg_t0;
         st.dbg_ticks = __builtin_amdgcn_s_memrealtime() - dbg_r0;
     }
+}
+
+extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
+                                                                 int n_streams) {
+    msk_frontend_body<1>(streams, cfg, n_streams);
+}
+// four streams per workgroup: one per SIMD of a CU by construction (see msk_frontend_body)
+extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_wg4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
+                                                                      int n_streams) {
+    msk_frontend_body<4>(streams, cfg, n_streams);
 }

@@ -98,11 +98,18 @@ struct PrevSums {
 };
 
 // std::arg on digital silence (ref :299): see k_frontend.hip::silence_pd for the derivation.
-__device__ __noinline__ double silence_pd_x4(double dr, double di, double pa, double pb, double pc, double pd_, double x40c,
-                                              double x40s, bool dom1, double fo_sum, uint32_t ksym) {
+// `ties` counts the windows with exactly one non-zero tap (opv_stream_state.edge_ties), as there.
+__device__ inline bool tone_tie(double p1, double p2, double p3, double p4) {
+    const double x = p1 * p2, y = p3 * p4;
+    return (p1 != 0.0 || p2 != 0.0 || p3 != 0.0 || p4 != 0.0) && fabs(y - x) <= 1e-12 * (fabs(x) + fabs(y));
+}
+__device__ __noinline__ double2 silence_pd_x4(double dr, double di, double pa, double pb, double pc, double pd_, double x40c,
+                                               double x40s, bool dom1, double fo_sum, uint32_t ksym,
+                                               double c1, double c2, double c3, double c4) {
     const double pr = dom1 ? pa + pb : pa - pb, pi = dom1 ? pc - pd_ : pc + pd_;
     const bool dom_zero = (dr == 0.0 && di == 0.0), prev_zero = (pr == 0.0 && pi == 0.0);
-    if (dom_zero == prev_zero) return 0.0;
+    if (dom_zero == prev_zero) return make_double2(0.0, 0.0);
+    const double tie = (prev_zero ? tone_tie(c1, c2, c3, c4) : tone_tie(pa, pb, pc, pd_)) ? 1.0 : 0.0;
     double th = (80.0 * kPi / kFs) * fo_sum;
     th -= kTwoPi * rint(th / kTwoPi);
     double sn, cs;
@@ -120,7 +127,7 @@ __device__ __noinline__ double silence_pd_x4(double dr, double di, double pa, do
     }
     const double qr = vr * er2 + vi * ei2;
     const double qi = vi * er2 - vr * ei2;
-    return (qr < 0.0 && qi < 0.0) ? kPi : 0.0;
+    return make_double2((qr < 0.0 && qi < 0.0) ? kPi : 0.0, tie);
 }
 
 }  // namespace
@@ -163,7 +170,8 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_x4(OpvStream* __
     const uint32_t n_avail = (uint32_t)st.n_avail;
     uint64_t n_soft = st.n_soft, total_samples = st.total_samples;
     uint32_t n_chunks = st.n_chunks;
-    int tail_done = st.tail_done, overflow = st.overflow;
+    int tail_done = st.tail_done, overflow = st.overflow, stalled = 0;
+    uint32_t edge_ties = st.edge_ties;
     const int eof = st.eof;
     const uint64_t cap_soft = st.cap_soft;
     if (cap_soft > (1ull << 28)) overflow = 1;
@@ -253,7 +261,8 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_x4(OpvStream* __
                 if (!eof || tail_done) go = false;
                 else { N = n_avail; last = true; }
             }
-            if (go && (overflow || (n_soft - soft_keep) + (uint64_t)(N / 38u + 2u) > cap_soft)) { overflow = 1; go = false; }
+            if (go && overflow) go = false;
+            if (go && (n_soft - soft_keep) + (uint64_t)(N / 38u + 2u) > cap_soft) { stalled = 1; go = false; }  // back-pressure, see k_frontend.hip
             if (go) {
                 in_call = true;
                 first = true;
@@ -383,9 +392,13 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_x4(OpvStream* __
                     const double sx = mkd((dhi(cx) & (int)0x80000000) | 0x3ff00000, 0);
                     pd = fma(sx, pd, fma(-sx, 1.57079632679489661923, 1.57079632679489661923));
                     pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));
-                    if (mx == 0.0)                                   // digital silence on either side
-                        pd = silence_pd_x4(dr, di, pv.a, pv.b, pv.c, pv.d, pv.x40c, pv.x40s, soft < 0.0, fo_sum,
-                                           (uint32_t)n_soft + (((soft_off - soft_off0) & soft_bmask) >> 3));
+                    if (mx == 0.0) {                                 // digital silence on either side
+                        const double2 sp = silence_pd_x4(dr, di, pv.a, pv.b, pv.c, pv.d, pv.x40c, pv.x40s, soft < 0.0, fo_sum,
+                                                         (uint32_t)n_soft + (((soft_off - soft_off0) & soft_bmask) >> 3),
+                                                         P1o, P2o, P3o, P4o);
+                        pd = sp.x;
+                        edge_ties += (uint32_t)sp.y;
+                    }
                     const double fo_used = fo;
                     fo = clampd(fma(kgain, pd, fo), -2000.0, 2000.0);
                     fo_sum += fo_used;
@@ -423,5 +436,6 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_x4(OpvStream* __
         st.fo_sum = fo_sum;
         st.origin = origin; st.n_soft = n_soft; st.total_samples = total_samples;
         st.n_chunks = n_chunks; st.tail_done = tail_done; st.overflow = overflow;
+        st.stalled = stalled; st.edge_ties = edge_ties;
     }
 }

@@ -1,4 +1,5 @@
-// k_offset_search.hip — coarse carrier-offset search, one 256-thread workgroup per stream.
+// k_offset_search.hip — coarse carrier-offset search, one 256-thread workgroup per stream, ONE pass over
+// the samples for all 134 candidates.
 //
 // Replaces MSKDemodulatorAFC::estimate_offset (reference src/opv-demod.cpp:131-202):
 // 121 coarse candidates (-1500..+1500 step 25 Hz, :135) then 13 fine ones (best-30..best+30
@@ -6,17 +7,30 @@
 // |sum s conj(lo1)|^2 + |sum s conj(lo2)|^2 (:143-158); strict '>' so the first maximum wins
 // (:161, :195).
 //
-// MI355X mapping. The reference accumulates the LO phase over all 40 000 samples; a
-// symbol's energy does not depend on the phase at the start of its window (|.|^2 removes a
-// common rotation), so each candidate needs only a 40-entry phasor table per tone,
-// exp(j i inc). The table is built in LDS by 80 lanes (fp64 sincos), then the 256 threads
-// each own symbols t, t+256, ... and run the two 40-tap complex correlations from L2-resident
-// int16 IQ (160 KB per stream, 16-byte loads). fp64 throughout: neighbouring candidates
-// differ by ~3e-7 (coarse) / ~1e-8 (fine) relative in energy, far above the
-// ~1e-13 re-association error of the block reduction but below fp32 resolution.
+// The reference evaluates 134 x 2 correlations per window. All of them are ONE function of the
+// candidate: with theta = 2 pi o / Fs and u_i = i - 19.5 (window centre),
+//     c_t(o) = sum_i x_i conj(lo_t[i])  =  (unit phasor) * sum_i y_t,i exp(-j u_i theta),
+//     y_t,i = x_i exp(-/+ j 2 pi i / 160)          (13 550 * 40 = Fs / 4: a fixed 40-entry table),
+// |u theta| <= 0.0865 over the whole +/-1530 Hz span, so the exponential is its Taylor series to
+// machine precision after ten terms (the eleventh is 6e-18):
+//     c_t(o) ~ sum_{k<10} (-j theta)^k m_t,k ,    m_t,k = sum_i y_t,i u_i^k / k!   (ten complex moments),
+// and the window's energy |c_t|^2 is a polynomial of degree 18 in theta whose coefficients are sums of
+// products m_k conj(m_l). Summed over windows and tones that is 19 real numbers per stream - after which
+// every candidate, coarse or fine, costs one Horner evaluation. Work per stream: 40 000 samples x 40 FMA
+// + 1000 windows x 220 FMA = 1.8 M FMA instead of 134 x 40 000 x 8 = 43 M, and the fine pass needs no
+// second look at the samples. The moments' weights (cos / sin table x u^k / k!) are wave-uniform: they
+// arrive through scalar loads and are scalar operands of the FMAs.
 //
-// Roofline: compute-trivial (134 x 1000 x 80 cMAC = 43 MFMA-free fp64 FMAs x4 per stream);
-// runs once per stream. Algorithmic bytes: 160 000 B read per stream.
+// Exactness. The energies agree with the reference's to ~1e-13 relative (its own phase accumulation
+// over 40 000 samples is no better); candidates in the tested captures are 1e-8 ... 3e-7 apart. Where the
+// winner is NOT clear - another candidate within kTieRel = 1e-11 relative - the contenders are re-evaluated the
+// reference's way (`exact_energy`: LO phases accumulated sample by sample from zero, products and sums in
+// the reference's order, windows summed in order; only libm's sin / cos are the device's), which shrinks
+// the undecidable band from 1e-13 to the last-place differences of sin / cos. The count of such
+// re-evaluations is reported (opv_stream_state.offset_ties).
+//
+// Roofline: 160 000 B read per stream, once. Compute: see above; no MFMA (the contraction is 40 x 40 per
+// window with weights that differ per tap - a GEMM only in name, and fp64).
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -27,6 +41,8 @@ namespace {
 constexpr double kTwoPi = 2.0 * 3.14159265358979323846;  // ref :43-44
 constexpr double kFs = 2168000.0;                        // ref :40
 constexpr double kFdev = 13550.0;                        // ref :42
+constexpr int kK = OPV_OFFS_TERMS;                       // Taylor terms (moments) per tone
+constexpr double kTieRel = 1e-11;                        // "not clearly below the best": 100x the agreement with the reference
 
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -34,10 +50,54 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
+// The reference's own evaluation of one candidate (ref :143-159, restated like the oracle's
+// candidate_energy): phases from zero, one addition per sample, never wrapped.
+// Workgroup-wide; `ph0` (2 x 1000 doubles) and `esym` (1000 doubles) are LDS scratch.
+__device__ double exact_energy(const int16_t* __restrict__ iq, int nsym, double offset, double* ph0, double* esym) {
+    const int tid = threadIdx.x;
+    const double i1 = kTwoPi * (-kFdev + offset) / kFs;   // ref :137
+    const double i2 = kTwoPi * (+kFdev + offset) / kFs;   // ref :138
+    __syncthreads();
+    if (tid == 0 || tid == 64) {                          // one lane per tone (two waves): 40 sequential adds per window
+        const double inc = tid ? i2 : i1;
+        double* out = ph0 + (tid ? 1000 : 0);
+        double p = 0.0;
+        for (int s = 0; s < nsym; ++s) {
+            out[s] = p;
+#pragma unroll 8
+            for (int i = 0; i < OPV_SPS; ++i) p += inc;
+        }
+    }
+    __syncthreads();
+    for (int s = tid; s < nsym; s += 256) {
+        double p1 = ph0[s], p2 = ph0[1000 + s];
+        double a1r = 0, a1i = 0, a2r = 0, a2i = 0;
+        const int16_t* x = iq + (size_t)s * (2 * OPV_SPS);
+        for (int i = 0; i < OPV_SPS; ++i) {
+            const double xr = (double)x[2 * i], xi = (double)x[2 * i + 1];
+            double s1, c1, s2, c2;
+            sincos(p1, &s1, &c1);
+            sincos(p2, &s2, &c2);
+            a1r += xr * c1 + xi * s1;                     // x conj(lo), contraction off (ref :151-152)
+            a1i += xi * c1 - xr * s1;
+            a2r += xr * c2 + xi * s2;
+            a2i += xi * c2 - xr * s2;
+            p1 += i1;
+            p2 += i2;
+        }
+        esym[s] = (a1r * a1r + a1i * a1i) + (a2r * a2r + a2i * a2i);   // ref :158
+    }
+    __syncthreads();
+    double total = 0.0;
+    for (int s = 0; s < nsym; ++s) total += esym[s];      // every thread, same order as the reference's loop
+    return total;
+}
+
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __restrict__ streams,
-                                                                   OpvGlobalCfg cfg) {
+// wtab: [40 taps][2 (cos, sin)][kK] doubles = cos(pi i/80) u^k/k!, sin(pi i/80) u^k/k!, u = i - 19.5 (host-made, opv_create)
+extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
+                                                                   const double* __restrict__ wtab) {
     OpvStream& st = streams[blockIdx.x];
     if (st.first_chunk_done) return;
 
@@ -63,66 +123,136 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
     const uint64_t test = n < (uint64_t)OPV_SPS * 1000u ? n : (uint64_t)OPV_SPS * 1000u;  // ref :141
     const int nsym = (int)(test / OPV_SPS);
 
-    __shared__ double2 tab[2][OPV_SPS];  // exp(j i inc_t), t = tone
-    __shared__ double part[4];
+    __shared__ double s_red[4][2 * kK - 1];
+    __shared__ double s_poly[2 * kK - 1];
+    __shared__ double s_e[134];
+    __shared__ double s_scratch[3000];       // exact_energy: 2 x 1000 window-start phases + 1000 window energies
     __shared__ double s_best_e, s_best, s_fine;
+    __shared__ int s_ties;
 
-    if (tid == 0) { s_best_e = 0.0; s_best = 0.0; s_fine = 0.0; }
+    // ---- one pass: moments per window, products accumulated into the 19 polynomial coefficients ----------
+    double ed[kK], eo[2 * kK - 1];           // sum |m_k|^2 (-> theta^2k) and sum over k > l of Re(rho m_k conj m_l) (-> theta^(k+l))
+#pragma unroll
+    for (int k = 0; k < kK; ++k) ed[k] = 0.0;
+#pragma unroll
+    for (int p = 0; p < 2 * kK - 1; ++p) eo[p] = 0.0;
     const int4* iq4 = reinterpret_cast<const int4*>(st.iq);
-
-    for (int c = 0; c < 134; ++c) {
-        __syncthreads();
-        double offset;
-        if (c < 121) offset = -1500.0 + 25.0 * c;           // exact in fp64, as the += 25 loop
-        else offset = (s_best - 30.0) + 5.0 * (c - 121);     // ref :169
-        if (tid < 2 * OPV_SPS) {
-            const int tone = tid / OPV_SPS, i = tid % OPV_SPS;
-            const double inc = kTwoPi * ((tone ? kFdev : -kFdev) + offset) / kFs;  // ref :137-138
-            double sn, cs;
-            sincos((double)i * inc, &sn, &cs);
-            tab[tone][i] = make_double2(cs, sn);
-        }
-        __syncthreads();
-
-        double acc = 0.0;
-        for (int sym = tid; sym < nsym; sym += 256) {
-            double a1r = 0, a1i = 0, a2r = 0, a2i = 0;
-            const int4* p = iq4 + (size_t)sym * (OPV_SPS / 4);
+    for (int sym = tid; sym < nsym; sym += 256) {
+        // A = sum xr cos w_k, B = sum xi cos w_k, C = sum xi sin w_k, D = sum xr sin w_k
+        double A[kK], B[kK], C[kK], D[kK];
 #pragma unroll
-            for (int q = 0; q < OPV_SPS / 4; ++q) {
-                const int4 v = p[q];
-                const int w[4] = {v.x, v.y, v.z, v.w};
+        for (int k = 0; k < kK; ++k) A[k] = B[k] = C[k] = D[k] = 0.0;
+        const int4* p = iq4 + (size_t)sym * (OPV_SPS / 4);
+        for (int q = 0; q < OPV_SPS / 4; ++q) {
+            const int4 v = p[q];
+            const int w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const double xr = (double)(int)(short)(w[k] & 0xFFFF);
-                    const double xi = (double)(w[k] >> 16);
-                    const double2 t1 = tab[0][4 * q + k], t2 = tab[1][4 * q + k];
-                    // x * conj(lo)  (ref :151-152)
-                    a1r = fma(xr, t1.x, fma(xi, t1.y, a1r));
-                    a1i = fma(xi, t1.x, fma(-xr, t1.y, a1i));
-                    a2r = fma(xr, t2.x, fma(xi, t2.y, a2r));
-                    a2i = fma(xi, t2.x, fma(-xr, t2.y, a2i));
+            for (int j = 0; j < 4; ++j) {
+                const double xr = (double)(int)(short)(w[j] & 0xFFFF);
+                const double xi = (double)(w[j] >> 16);
+                const double* wt = wtab + (size_t)(4 * q + j) * (2 * kK);   // wave-uniform address: scalar loads
+#pragma unroll
+                for (int k = 0; k < kK; ++k) {
+                    const double wc = wt[k], ws = wt[kK + k];
+                    A[k] = fma(xr, wc, A[k]);
+                    B[k] = fma(xi, wc, B[k]);
+                    C[k] = fma(xi, ws, C[k]);
+                    D[k] = fma(xr, ws, D[k]);
                 }
             }
-            acc += (a1r * a1r + a1i * a1i) + (a2r * a2r + a2i * a2i);  // ref :158
         }
-        acc = wave_sum(acc);
-        if ((tid & 63) == 0) part[tid >> 6] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            const double e = (part[0] + part[1]) + (part[2] + part[3]);
-            st.energies[c] = e;
-            if (e > s_best_e) {  // strict: first maximum wins (ref :161, :195)
-                s_best_e = e;
-                if (c < 121) s_best = offset; else s_fine = offset;
+        // tone 1 (-13550 + o): y = x exp(+j pi i/80) -> m = (A - C, D + B); tone 2: y = x exp(-j pi i/80) -> m = (A + C, B - D)
+#pragma unroll
+        for (int tone = 0; tone < 2; ++tone) {
+            double mr[kK], mi[kK];
+#pragma unroll
+            for (int k = 0; k < kK; ++k) {
+                mr[k] = tone ? A[k] + C[k] : A[k] - C[k];
+                mi[k] = tone ? B[k] - D[k] : D[k] + B[k];
             }
-            if (c == 120) s_fine = s_best;  // ref :168
+            // |sum_k (-j theta)^k m_k|^2 = sum_k theta^2k |m_k|^2 + 2 sum_{k>l} theta^(k+l) Re((-j)^(k-l) m_k conj m_l)
+#pragma unroll
+            for (int k = 0; k < kK; ++k) {
+                ed[k] = fma(mr[k], mr[k], fma(mi[k], mi[k], ed[k]));
+#pragma unroll
+                for (int l = 0; l < k; ++l) {
+                    const int r = (k - l) & 3;            // (-j)^r = 1, -j, -1, j
+                    if (r == 0) eo[k + l] = fma(mr[k], mr[l], fma(mi[k], mi[l], eo[k + l]));          // + Re g
+                    else if (r == 1) eo[k + l] = fma(mi[k], mr[l], fma(-mr[k], mi[l], eo[k + l]));    // + Im g
+                    else if (r == 2) eo[k + l] = fma(-mr[k], mr[l], fma(-mi[k], mi[l], eo[k + l]));   // - Re g
+                    else eo[k + l] = fma(-mi[k], mr[l], fma(mr[k], mi[l], eo[k + l]));                // - Im g
+                }
+            }
         }
     }
+#pragma unroll
+    for (int p = 0; p < 2 * kK - 1; ++p) {
+        double v = 2.0 * eo[p];
+        if ((p & 1) == 0) v += ed[p / 2];
+        v = wave_sum(v);
+        if ((tid & 63) == 0) s_red[tid >> 6][p] = v;
+    }
+    if (tid == 0) { s_best_e = 0.0; s_best = 0.0; s_fine = 0.0; s_ties = 0; }
     __syncthreads();
+    if (tid < 2 * kK - 1) s_poly[tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+    __syncthreads();
+    auto poly_energy = [&](double offset) {
+        const double th = kTwoPi * offset / kFs;
+        double e = s_poly[2 * kK - 2];
+#pragma unroll
+        for (int p = 2 * kK - 3; p >= 0; --p) e = fma(e, th, s_poly[p]);
+        return e;
+    };
+    // Decide among candidates [c0, c1) the way the reference's loop does (strict '>' against the running best),
+    // after re-evaluating in its own order every candidate that is within 1e-9 of the best energy in play
+    // (the running best included) unless the winner is clear.
+    auto decide = [&](int c0, int c1, double base_offset, double step, bool fine) {
+        if (tid >= c0 && tid < c1) s_e[tid] = poly_energy(base_offset + step * (double)(tid - c0));
+        __syncthreads();
+        double top = s_best_e;
+        for (int c = c0; c < c1; ++c) top = fmax(top, s_e[c]);
+        if (top > 0.0) {
+            const double bar = top * (1.0 - kTieRel);
+            // (the fine candidate AT the coarse winner's offset repeats its evaluation: identical by construction,
+            // here as in the reference, and never '>' - it is no contender)
+            auto in_play = [&](int c) { return s_e[c] >= bar && !(fine && base_offset + step * (double)(c - c0) == s_best); };
+            int contenders = (fine && s_best_e >= bar) ? 1 : 0;   // the coarse winner defends its energy
+            for (int c = c0; c < c1; ++c) contenders += in_play(c);
+            if (contenders > 1) {                         // workgroup-uniform: every thread sees the same LDS values
+                for (int c = c0; c < c1; ++c) {
+                    if (!in_play(c)) continue;
+                    const double e = exact_energy(st.iq, nsym, base_offset + step * (double)(c - c0), s_scratch, s_scratch + 2000);
+                    __syncthreads();
+                    if (tid == 0) { s_e[c] = e; ++s_ties; }
+                    __syncthreads();
+                }
+                if (fine && s_best_e >= bar) {
+                    const double e = exact_energy(st.iq, nsym, s_best, s_scratch, s_scratch + 2000);
+                    __syncthreads();
+                    if (tid == 0) { s_best_e = e; ++s_ties; }
+                }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) {
+            for (int c = c0; c < c1; ++c) {
+                st.energies[c] = s_e[c];
+                if (s_e[c] > s_best_e) {                  // strict: first maximum wins (ref :161, :195)
+                    s_best_e = s_e[c];
+                    if (fine) s_fine = base_offset + step * (double)(c - c0);
+                    else s_best = base_offset + step * (double)(c - c0);
+                }
+            }
+            if (!fine) s_fine = s_best;                   // ref :168
+        }
+        __syncthreads();
+    };
+    decide(0, 121, -1500.0, 25.0, false);                 // exact in fp64, as the reference's += 25 loop (:135)
+    decide(121, 134, s_best - 30.0, 5.0, true);           // ref :169
     if (tid == 0) {
         st.est_offset = s_fine;
         st.freq_offset = s_fine;  // demod.set_freq_offset(est) (ref :1033 / :1167)
+        st.est_ties = (uint32_t)s_ties;
         st.first_chunk_done = 1;
     }
 }

@@ -57,24 +57,28 @@ extern "C" __global__ __launch_bounds__(64) void k_sync_track(OpvStream* __restr
     int overflow = st.overflow;
     if (lane == 0) st.dec_from = n_frames;
 
+    // The event log (the reference's stderr lines) is LOSSY: a ring of the most recent cap_events entries; a
+    // consumer that never reads it (opv-modem sends the child's stderr to /dev/null) loses the oldest lines and
+    // nothing else. Frames are not: a full ring of unpopped frames stops the tracker in front of the release
+    // (state untouched) until opv_pop_frames has made room.
     auto event = [&](int kind, int count, uint64_t sym, double corr, double raw) {
-        if (n_events - st.events_popped < st.cap_events) {  // ring of unread events
-            if (lane == 0) {
-                OpvEventRec& e = st.events[n_events % st.cap_events];
-                e.kind = kind; e.count = count; e.sym_idx = sym; e.corr = corr; e.raw = raw;
-            }
-        } else overflow = 1;
+        if (lane == 0) {
+            OpvEventRec& e = st.events[n_events % st.cap_events];
+            e.kind = kind; e.count = count; e.sym_idx = sym; e.corr = corr; e.raw = raw;
+        }
         ++n_events;
     };
+    int sync_ok = st.trk_sync_ok, stalled = 0;
+    auto frames_full = [&]() { return n_frames - st.frames_popped >= st.cap_frames; };
     auto release = [&](uint64_t at) {  // ref :660-668 / :721-729
-        if (n_frames - st.frames_popped < st.cap_frames) {  // ring of unread frames
-            if (lane == 0) {
-                OpvFrameRec& f = st.frec[n_frames % st.cap_frames];
-                f.payload_sym = anchor + 1;
-                f.release_sym = at;
-                f.quality = quality;
-            }
-        } else overflow = 1;
+        if (lane == 0) {
+            OpvFrameRec& f = st.frec[n_frames % st.cap_frames];
+            f.payload_sym = anchor + 1;
+            f.release_sym = at;
+            f.quality = quality;
+            f.sync_ok = sync_ok;
+            f.pad = 0;
+        }
         ++n_frames;
         collecting = 0;
     };
@@ -98,6 +102,7 @@ extern "C" __global__ __launch_bounds__(64) void k_sync_track(OpvStream* __restr
                     const uint64_t s = pos + (uint64_t)first;
                     const double nrm = __shfl(c.norm, first, 64), raw = __shfl(c.raw, first, 64);
                     state = 1;  // VERIFYING
+                    sync_ok = 1;
                     quality = nrm;
                     anchor = s;  // symbols_since_sync_ = 0 here (ref :645)
                     collecting = 1;
@@ -112,6 +117,7 @@ extern "C" __global__ __launch_bounds__(64) void k_sync_track(OpvStream* __restr
         } else if (state == 1) {  // VERIFYING (ref :657-680)
             const uint64_t r = anchor + OPV_CODED;
             if (r >= n) break;
+            if (frames_full()) { stalled = 2; break; }
             release(r);
             state = 2;
             misses = 0;
@@ -121,6 +127,7 @@ extern "C" __global__ __launch_bounds__(64) void k_sync_track(OpvStream* __restr
             if (collecting) {
                 const uint64_t r = anchor + OPV_CODED;
                 if (r >= n) break;
+                if (frames_full()) { stalled = 2; break; }
                 release(r);
                 next = r + 1;
                 continue;
@@ -133,6 +140,7 @@ extern "C" __global__ __launch_bounds__(64) void k_sync_track(OpvStream* __restr
                 misses = 0;
                 quality = k.norm;
                 collecting = 1;
+                sync_ok = 1;
                 event(3, 0, c, k.norm, k.raw);
             } else {
                 ++misses;
@@ -145,6 +153,7 @@ extern "C" __global__ __launch_bounds__(64) void k_sync_track(OpvStream* __restr
                 }
                 quality = k.norm;  // flywheel (ref :709-712)
                 collecting = 1;
+                sync_ok = 0;
             }
             anchor = c;  // symbols_since_sync_ = 0 (ref :716)
         }
@@ -153,6 +162,7 @@ extern "C" __global__ __launch_bounds__(64) void k_sync_track(OpvStream* __restr
     if (lane == 0) {
         st.trk_state = state; st.trk_collecting = collecting; st.trk_misses = misses;
         st.trk_anchor = anchor; st.trk_next = next; st.trk_quality = quality;
-        st.n_frames = n_frames; st.n_events = n_events; st.overflow = overflow;
+        st.n_frames = n_frames; st.n_events = n_events; st.trk_sync_ok = sync_ok;
+        st.stalled |= stalled;  // (the front-end, which runs first, rewrote bit 0 this round)
     }
 }

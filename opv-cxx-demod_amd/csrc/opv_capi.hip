@@ -17,11 +17,12 @@
 #include "opv_device.h"
 #include "opv_tx_internal.h"
 
-extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg);
-extern "C" __global__ void k_msk_frontend(OpvStream*, OpvGlobalCfg);
+extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg, const double*);
+extern "C" __global__ void k_msk_frontend(OpvStream*, OpvGlobalCfg, int);
+extern "C" __global__ void k_msk_frontend_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_sync_track(OpvStream*);
-extern "C" __global__ void k_frame_decode(OpvStream*);
+extern "C" __global__ void k_frame_decode(OpvStream*, uint32_t);
 extern "C" __global__ void k_decode_payloads(const double*, uint32_t, uint8_t*, int32_t*, int8_t*, int8_t*, uint8_t*);
 extern "C" __global__ void k_channel(const int4*, int4*, uint64_t, double, double, double, uint64_t);
 extern "C" __global__ void k_resample_clock(const int*, uint64_t, int*, uint64_t, double);
@@ -45,6 +46,9 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
         if (_e != hipSuccess) return fail(OPV_EHIP, #expr, _e);   \
     } while (0)
 
+// one wave per stream, four of them per workgroup: from the stream count at which single-wave workgroups start to
+// double up on SIMDs (k_frontend.hip: msk_frontend_body) up to the count its two workgroups per CU (LDS) can hold at once
+constexpr int kFrontendWg4MinStreams = 512, kFrontendWg4MaxStreams = 2048;
 constexpr int kFrontendX4MinStreams = 8192;  // measured cross-over on MI355X (front-end alone 173 vs 112 GS/s there, 87 vs 109 at 4096)
 
 struct StreamIn {  // host -> device per-round update
@@ -91,6 +95,7 @@ struct HostStream {
     uint64_t last_round_avail = 0;
     uint32_t popped = 0;        // frame records already handed out
     uint32_t events_popped = 0;
+    uint32_t events_dropped = 0;       // overwritten in the (lossy) event ring before they were read
     int32_t decoded = 0, perfect = 0;  // over popped frames (`decoded` / `perfect` of main(), ref :1053-1054)
 };
 
@@ -120,6 +125,7 @@ struct opv_ctx {
     uint8_t* d_frames = nullptr;
     int32_t* d_metrics = nullptr;
     int32_t* d_counts = nullptr;
+    double* d_offs_wtab = nullptr;      // k_offset_search's moment weights: [40 taps][cos, sin][OPV_OFFS_TERMS]
     uint64_t cap_soft = 0;
     uint32_t cap_frames = 0, cap_events = 0, cap_chunks = 0;
     bool mirror_valid = false;
@@ -236,6 +242,20 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
     HIPCHK_C(hipMalloc(&c->d_frames, (size_t)OPV_FB * c->cap_frames * S));
     HIPCHK_C(hipMalloc(&c->d_metrics, sizeof(int32_t) * c->cap_frames * S));
     HIPCHK_C(hipMalloc(&c->d_counts, sizeof(int32_t) * S));
+    {   // cos / sin(pi i / 80) x u^k / k!, u = i - 19.5: the tone tables of the offset search folded into its Taylor weights
+        std::vector<double> w((size_t)OPV_SPS * 2 * OPV_OFFS_TERMS);
+        for (int i = 0; i < OPV_SPS; ++i) {
+            const double u = (double)i - 19.5, cs = std::cos(M_PI * i / 80.0), sn = std::sin(M_PI * i / 80.0);
+            double t = 1.0;                                // u^k / k!
+            for (int k = 0; k < OPV_OFFS_TERMS; ++k) {
+                w[((size_t)i * 2 + 0) * OPV_OFFS_TERMS + k] = cs * t;
+                w[((size_t)i * 2 + 1) * OPV_OFFS_TERMS + k] = sn * t;
+                t = t * u / (double)(k + 1);
+            }
+        }
+        HIPCHK_C(hipMalloc(&c->d_offs_wtab, sizeof(double) * w.size()));
+        HIPCHK_C(hipMemcpy(c->d_offs_wtab, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice));
+    }
     HIPCHK_C(hipMemsetAsync(c->d_frames, 0, (size_t)OPV_FB * c->cap_frames * S, c->stream));
     HIPCHK_C(hipMemsetAsync(c->d_counts, 0, sizeof(int32_t) * S, c->stream));
     k_fill_i32<<<256, 256, 0, c->stream>>>(c->d_metrics, INT32_MIN, (size_t)c->cap_frames * S);
@@ -284,7 +304,7 @@ extern "C" void opv_destroy(opv_ctx* c) {
     }
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_counts, c->d_tx_phases};
+    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_counts, c->d_tx_phases, c->d_offs_wtab};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -425,21 +445,24 @@ extern "C" int opv_process(opv_ctx* c) {
     k_apply_inputs<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_in, S);
     const bool tm = c->timing;
     if (tm) HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    k_offset_search<<<S, 256, 0, c->stream>>>(c->d_streams, g);
+    k_offset_search<<<S, 256, 0, c->stream>>>(c->d_streams, g, c->d_offs_wtab);
     if (tm) { HIPCHK(hipEventRecord(c->ev[1], c->stream)); HIPCHK(hipEventRecord(c->ev[2], c->stream)); }
     // one wave per stream has the shortest per-symbol latency (what counts while SIMDs are idle, and up to
     // two waves per SIMD); four streams per wave issue 137 instead of 213 instructions per symbol and
     // stream, which only pays once there are more streams than the chip has wave slots for
     const bool x4 = c->frontend == 4 || (c->frontend == 0 && S >= kFrontendX4MinStreams);
     if (x4) k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
-    else k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g);
+    else if (S > kFrontendWg4MinStreams && S <= kFrontendWg4MaxStreams)
+        k_msk_frontend_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);
+    else k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g, S);
     if (tm) { HIPCHK(hipEventRecord(c->ev[3], c->stream)); HIPCHK(hipEventRecord(c->ev[4], c->stream)); }
     k_sync_track<<<S, 64, 0, c->stream>>>(c->d_streams);
     if (tm) { HIPCHK(hipEventRecord(c->ev[5], c->stream)); HIPCHK(hipEventRecord(c->ev[6], c->stream)); }
     // frames a stream can release this round: new symbols / 2168 plus what was pending
     uint64_t fr = max_new / (uint64_t)(OPV_FSYMS * 38) + 4;
     if (fr > c->cap_frames) fr = c->cap_frames;
-    k_frame_decode<<<dim3((unsigned)fr, (unsigned)S), 64, 0, c->stream>>>(c->d_streams);
+    if (fr * (uint64_t)S > 0x7FFFFFFFull) return fail(OPV_EINVAL, "opv_process: streams x frames per round exceeds the grid limit");
+    k_frame_decode<<<(unsigned)(fr * (uint64_t)S), 64, 0, c->stream>>>(c->d_streams, (uint32_t)fr);
     if (tm) { HIPCHK(hipEventRecord(c->ev[7], c->stream)); c->timing_valid = true; }
     k_collect_counts<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_counts, S);
     HIPCHK(hipGetLastError());
@@ -526,7 +549,7 @@ extern "C" long opv_pop_frames(opv_ctx* c, int s, uint8_t* out, size_t cap, opv_
     if (int r = check_stream(c, s)) return r;
     if (int r = c->refresh()) return r;
     const OpvStream& st = c->mirror[s];
-    if (st.overflow) return fail(OPV_ECAPACITY, "a device log overflowed (pop more often or raise opv_cfg.max_samples)");
+    if (st.overflow) return fail(OPV_EINVAL, "opv_cfg.max_samples too large for the soft-symbol ring (internal limit 2^28 symbols)");
     HostStream& h = c->hs[s];
     const uint32_t nf = st.n_frames;
     if (h.popped >= nf || cap == 0) return 0;
@@ -554,7 +577,7 @@ extern "C" long opv_pop_frames(opv_ctx* c, int s, uint8_t* out, size_t cap, opv_
             if (out) std::memcpy(out + w * OPV_FB, fr.data() + (size_t)k * OPV_FB, OPV_FB);
             if (meta) {
                 meta[w].viterbi_metric = met[k];
-                meta[w].reserved = 0;
+                meta[w].sync_ok = rec[k].sync_ok;
                 meta[w].sync_quality = rec[k].quality;
                 meta[w].release_symbol = rec[k].release_sym;
                 meta[w].payload_symbol = rec[k].payload_sym;
@@ -565,6 +588,7 @@ extern "C" long opv_pop_frames(opv_ctx* c, int s, uint8_t* out, size_t cap, opv_
         }
         if (stop) break;
     }
+    if (f != h.popped && st.stalled) h.dirty = true;  // room again: the next opv_process resumes the stream
     h.popped = f;
     return (long)w;
 }
@@ -575,6 +599,10 @@ extern "C" long opv_pop_events(opv_ctx* c, int s, opv_event* out, size_t cap) {
     const OpvStream& st = c->mirror[s];
     HostStream& h = c->hs[s];
     const uint32_t ne = st.n_events;
+    if (ne - h.events_popped > st.cap_events) {  // lossy ring: the oldest unread entries have been overwritten
+        h.events_dropped += (ne - h.events_popped) - st.cap_events;
+        h.events_popped = ne - st.cap_events;
+    }
     if (h.events_popped >= ne || cap == 0 || !out) return 0;
     uint32_t n = ne - h.events_popped;
     if (n > cap) n = (uint32_t)cap;
@@ -604,6 +632,11 @@ extern "C" int opv_get_state(opv_ctx* c, int s, opv_stream_state* out) {
     const HostStream& h = c->hs[s];
     out->frames_decoded = h.decoded;
     out->frames_perfect = h.perfect;
+    out->events_dropped = h.events_dropped;
+    if (st.n_events - h.events_popped > st.cap_events) out->events_dropped += (st.n_events - h.events_popped) - st.cap_events;
+    out->edge_ties = st.edge_ties;
+    out->offset_ties = (int32_t)st.est_ties;
+    out->stalled = st.stalled;
     if (st.n_frames > h.popped) {  // released but not popped yet
         uint32_t n = st.n_frames - h.popped;
         if (n > st.cap_frames) n = st.cap_frames;
@@ -612,7 +645,7 @@ extern "C" int opv_get_state(opv_ctx* c, int s, opv_stream_state* out) {
         for (int32_t m : met)
             if (m >= 0) { out->frames_decoded++; if (m == 0) out->frames_perfect++; }
     }
-    return st.overflow ? fail(OPV_ECAPACITY, "a device log overflowed") : OPV_OK;
+    return st.overflow ? fail(OPV_EINVAL, "opv_cfg.max_samples too large for the soft-symbol ring") : OPV_OK;
 }
 
 extern "C" int opv_device_frames(opv_ctx* c, const uint8_t** d_frames, const int32_t** d_metrics,

@@ -14,6 +14,8 @@
 #define OPV_CHUNK 86720
 #define OPV_SYNC_WORD 0x02B8DBu
 
+#define OPV_OFFS_TERMS 10                     // Taylor terms of the offset search's one-pass evaluation (k_offset_search.hip)
+
 #define OPV_TILE_SAMPLES 2048                 // HBM->LDS staging unit of int16 IQ (two tiles = a power-of-two ring)
 #define OPV_TILE_BYTES (OPV_TILE_SAMPLES * 4) // 8192 B = 8 wave-wide 16 B/lane loads
 
@@ -21,6 +23,8 @@ struct OpvFrameRec {       // written by k_sync_track, read by k_frame_decode an
     uint64_t payload_sym;  // index of first payload soft symbol in the soft log
     uint64_t release_sym;  // symbol index at which the reference releases the frame
     double quality;        // sync_quality_
+    int32_t sync_ok;       // 1: this frame's sync word passed its check (HUNTING hit, or LOCKED corr >= 0.70); 0: flywheel
+    int32_t pad;
 };
 
 struct OpvEventRec {  // mirrors opv_event
@@ -61,6 +65,7 @@ struct OpvStream {
     double x40c, x40s;
     double fo_sum;            // sum of the freq_offset used by every symbol so far (absolute LO phase, see k_frontend)
     double est_offset;        // NaN until estimate_offset ran
+    uint32_t est_ties, pad2;  // offset-search candidates re-evaluated in the reference's order (near-ties)
     double energies[134];     // offset-search tap
 
     // ---- chunker carry (ref :1012-1076) ----
@@ -70,7 +75,12 @@ struct OpvStream {
     uint32_t n_chunks;
     int32_t first_chunk_done; // offset search done or skipped
     int32_t tail_done;        // EOF tail processed
-    int32_t overflow;         // a log ran out of capacity
+    int32_t overflow;         // configuration error (soft ring too large for 32-bit byte offsets)
+    int32_t stalled;          // back-pressure, cleared every round: bit 0 = the front-end skipped a demodulate() call
+                              // because unread soft symbols fill the ring, bit 1 = the tracker stopped in front of a
+                              // frame release because the ring of unpopped frames is full (resumes after opv_pop_frames)
+    uint32_t edge_ties;       // symbols next to digital silence whose tone choice the reference decides by the rounding of
+                              // its own LO (exactly one non-zero tap in the window; see k_frontend.hip::silence_pd)
 
     // ---- SyncTracker carry (ref :759-780), expressed on soft-log positions ----
     int32_t trk_state;        // OPV_HUNTING / VERIFYING / LOCKED
@@ -79,6 +89,7 @@ struct OpvStream {
     uint64_t trk_next;        // next symbol index the tracker has not consumed yet
     double trk_quality;
     int32_t trk_misses;
+    int32_t trk_sync_ok;      // whether the pending payload's sync word passed its check
     uint32_t n_frames;        // frames released (total_frames_)
     uint32_t n_events;
     uint32_t dec_from;        // first frame record k_frame_decode must handle this round

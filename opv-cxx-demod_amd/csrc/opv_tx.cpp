@@ -5,7 +5,7 @@
 // (:339-361), CCSDS randomiser (:97-113), K=7 r=1/2 encoder (:120-136, last byte first, MSB
 // first :186-196), 67x32 interleaver with in-byte bit reversal (:142-153), sync word MSB
 // first (:315-321) and the parallel-tone MSK modulator (:219-291) followed by 100 zero
-// symbols (:528-529). Pinned by sha256 against `opv-mod` output (tests/test_host_tx.py).
+// symbols (:528-529). Pinned by sha256 against `opv-mod` output (tests/test_capi_and_host.py).
 //
 // Design (not the reference's): the per-symbol tone/sign sequence and the NCO phases at each
 // frame boundary are produced by one cheap sequential pass (the NCOs free-run with the

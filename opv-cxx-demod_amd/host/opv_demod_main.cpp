@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -56,27 +57,56 @@ void print_event(const opv_event& e) {  // ref :651,677,695,699,705
     }
 }
 
-void print_frame(int num, const uint8_t* f, int metric, double sync) {  // ref :907-938
-    fprintf(stderr, "┌─────────────────────────────────────────────────────────────────┐\n");
-    fprintf(stderr, "│ FRAME %4d  │  Sync: %.3f  │  Metric: %5d", num, sync, metric);
-    if (metric == 0) fprintf(stderr, " (perfect)");
-    fprintf(stderr, "\n├─────────────────────────────────────────────────────────────────┤\n");
-    fprintf(stderr, "│ Station ID:  %-12s (Base-40)\n", base40(f).c_str());
-    const uint32_t tok = ((uint32_t)f[6] << 16) | ((uint32_t)f[7] << 8) | f[8];
-    fprintf(stderr, "│ Token:       0x%06X%s\n", tok, tok == 0xBBAADD ? " (default)" : "");
-    const uint32_t res = ((uint32_t)f[9] << 16) | ((uint32_t)f[10] << 8) | f[11];
-    fprintf(stderr, "│ Reserved:    0x%06X\n", res);
-    fprintf(stderr, "├─────────────────────────────────────────────────────────────────┤\n");
-    fprintf(stderr, "│ Hex Dump:                                                       │\n");
-    for (size_t i = 0; i < OPV_FRAME_BYTES; i += 16) {
-        fprintf(stderr, "│ %02zx: ", i);
-        for (size_t j = i; j < i + 16 && j < OPV_FRAME_BYTES; ++j) fprintf(stderr, "%02X ", f[j]);
-        for (size_t j = OPV_FRAME_BYTES; j < i + 16; ++j) fprintf(stderr, "   ");
-        fprintf(stderr, " │");
-        for (size_t j = i; j < i + 16 && j < OPV_FRAME_BYTES; ++j) fprintf(stderr, "%c", (f[j] >= 0x20 && f[j] < 0x7F) ? f[j] : '.');
-        fprintf(stderr, "│\n");
+// The per-frame box of the reference (ref :907-938) is part of the process contract (stderr text
+// byte for byte), so its literals are fixed; it is assembled here in one buffer and handed to stderr with a
+// single write, a row at a time from a small table of field formatters.
+namespace box {
+constexpr const char* kTop = "┌─────────────────────────────────────────────────────────────────┐\n";
+constexpr const char* kSep = "├─────────────────────────────────────────────────────────────────┤\n";
+constexpr const char* kBot = "└─────────────────────────────────────────────────────────────────┘\n\n";
+
+inline uint32_t be24(const uint8_t* p) { return ((uint32_t)p[0] << 16) | ((uint32_t)p[1] << 8) | p[2]; }
+
+struct Text {
+    std::string s;
+    void add(const char* fmt, ...) __attribute__((format(printf, 2, 3))) {
+        char tmp[160];
+        va_list ap;
+        va_start(ap, fmt);
+        const int n = vsnprintf(tmp, sizeof tmp, fmt, ap);
+        va_end(ap);
+        if (n > 0) s.append(tmp, (size_t)std::min<int>(n, (int)sizeof tmp - 1));
     }
-    fprintf(stderr, "└─────────────────────────────────────────────────────────────────┘\n\n");
+};
+
+// one 16-byte row of the dump: offset, hex column padded to 16 places, printable column
+void dump_row(Text& t, const uint8_t* f, size_t at) {
+    const size_t n = std::min<size_t>(16, OPV_FRAME_BYTES - at);
+    std::string hex, asc;
+    char h[4];
+    for (size_t k = 0; k < 16; ++k) {
+        if (k < n) { snprintf(h, sizeof h, "%02X ", f[at + k]); hex += h; asc += (f[at + k] >= 0x20 && f[at + k] < 0x7F) ? (char)f[at + k] : '.'; }
+        else hex += "   ";
+    }
+    t.add("│ %02zx: %s │%s│\n", at, hex.c_str(), asc.c_str());
+}
+}  // namespace box
+
+void print_frame(int num, const uint8_t* f, int metric, double sync) {
+    box::Text t;
+    t.s.reserve(2048);
+    t.s += box::kTop;
+    t.add("│ FRAME %4d  │  Sync: %.3f  │  Metric: %5d%s\n", num, sync, metric, metric == 0 ? " (perfect)" : "");
+    t.s += box::kSep;
+    t.add("│ Station ID:  %-12s (Base-40)\n", base40(f).c_str());
+    const uint32_t token = box::be24(f + 6);
+    t.add("│ Token:       0x%06X%s\n", token, token == 0xBBAADD ? " (default)" : "");
+    t.add("│ Reserved:    0x%06X\n", box::be24(f + 9));
+    t.s += box::kSep;
+    t.s += "│ Hex Dump:                                                       │\n";
+    for (size_t at = 0; at < OPV_FRAME_BYTES; at += 16) box::dump_row(t, f, at);
+    t.s += box::kBot;
+    fwrite(t.s.data(), 1, t.s.size(), stderr);
 }
 
 struct Options {

@@ -10,7 +10,11 @@
 // src/opv-demod.cpp:221) is unchanged.
 //
 //   opv-rx-bridge [-H host] [-P base_port] [-o hz] [-a alpha] [--device n] [-q] [input ...]
-//     inputs: files or FIFOs with int16 I/Q; none = stdin as the only stream.
+//     inputs, one stream each ("N stdin/UDP sources"):
+//       PATH      file or FIFO with int16 I/Q
+//       -         stdin (also the only stream when no input is named, like `opv-modem -R`)
+//       udp:PORT  IQ bytes arriving as UDP datagrams on 127.0.0.1:PORT (what a network SDR front-end sends);
+//                 a zero-length datagram ends the stream
 #include <arpa/inet.h>
 #include <fcntl.h>
 #include <netinet/in.h>
@@ -30,7 +34,7 @@
 namespace {
 struct Input {
     int fd = -1;
-    bool eof = false;
+    bool eof = false, udp = false;
     unsigned char carry[4];
     size_t ncarry = 0;
     long frames = 0, perfect = 0;
@@ -60,8 +64,20 @@ int main(int argc, char** argv) {
     const int S = paths.empty() ? 1 : (int)paths.size();
     std::vector<Input> in(S);
     for (int k = 0; k < S; ++k) {
-        in[k].fd = paths.empty() ? STDIN_FILENO : open(paths[k].c_str(), O_RDONLY | O_NONBLOCK);
-        if (in[k].fd < 0) { perror(paths[k].c_str()); return 2; }
+        const std::string p = paths.empty() ? "-" : paths[k];
+        if (p == "-") in[k].fd = STDIN_FILENO;
+        else if (p.rfind("udp:", 0) == 0) {
+            in[k].udp = true;
+            in[k].fd = socket(AF_INET, SOCK_DGRAM, 0);
+            sockaddr_in a{};
+            a.sin_family = AF_INET;
+            a.sin_port = htons((uint16_t)atoi(p.c_str() + 4));
+            a.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+            const int big = 8 << 20;
+            if (in[k].fd >= 0) setsockopt(in[k].fd, SOL_SOCKET, SO_RCVBUF, &big, sizeof big);
+            if (in[k].fd < 0 || bind(in[k].fd, (sockaddr*)&a, sizeof a) < 0) { perror(p.c_str()); return 2; }
+        } else in[k].fd = open(p.c_str(), O_RDONLY | O_NONBLOCK);
+        if (in[k].fd < 0) { perror(p.c_str()); return 2; }
         fcntl(in[k].fd, F_SETFL, fcntl(in[k].fd, F_GETFL) | O_NONBLOCK);
     }
     const int sock = socket(AF_INET, SOCK_DGRAM, 0);
@@ -87,8 +103,10 @@ int main(int argc, char** argv) {
 
     std::vector<pollfd> pfd(S);
     constexpr size_t kRead = 16384;                       // opv-modem's read size (src/opv-modem.cpp:734,753)
-    std::vector<unsigned char> bufs((size_t)S * (kRead + 4));   // one read buffer per stream: a poll round is ONE batched push
-    std::vector<int> ids;
+    constexpr size_t kDgram = 65536;                      // a UDP datagram is taken whole (<= 65507 bytes of payload)
+    constexpr size_t kRound = 1u << 20;                   // at most this much per stream and poll round (0.12 s of IQ)
+    std::vector<unsigned char> bufs((size_t)S * (kRound + kDgram + 4));   // one buffer per stream: a poll round is ONE batched push
+    std::vector<int> ids, pending_flush;
     std::vector<const int16_t*> ptrs;
     std::vector<size_t> lens;
     uint8_t frames[64 * OPV_FRAME_BYTES];
@@ -118,28 +136,37 @@ int main(int argc, char** argv) {
         for (int k = 0; k < S; ++k) {
             if (in[k].eof) continue;
             if (!(pfd[k].revents & (POLLIN | POLLHUP))) continue;
-            unsigned char* buf = bufs.data() + (size_t)k * (kRead + 4);
+            // everything the source has ready goes into this round (reads of 16 KB like the reference's loop, a
+            // datagram at a time for UDP): one push + one opv_process per poll round, however fast the data arrives
+            unsigned char* buf = bufs.data() + (size_t)k * (kRound + kDgram + 4);
             memcpy(buf, in[k].carry, in[k].ncarry);
-            const ssize_t r = read(in[k].fd, buf + in[k].ncarry, kRead);
-            if (r < 0) continue;  // EAGAIN
-            if (r == 0) {
-                in[k].eof = true;
-                --open_streams;
-                if (opv_flush(ctx, k) < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
-                any = true;
-                continue;
+            size_t have = in[k].ncarry;
+            bool ended = false;
+            while (have < kRound) {
+                const ssize_t r = read(in[k].fd, buf + have, in[k].udp ? kDgram : kRead);
+                if (r < 0) break;                         // EAGAIN: drained for now
+                if (r == 0) { ended = true; break; }      // EOF / the empty datagram that ends a UDP stream
+                have += (size_t)r;
             }
-            const size_t have = in[k].ncarry + (size_t)r, ns = have / 4;
-            if (ns) { ids.push_back(k); ptrs.push_back(reinterpret_cast<const int16_t*>(buf)); lens.push_back(ns); }
+            const size_t ns = have / 4;
+            if (ns) { ids.push_back(k); ptrs.push_back(reinterpret_cast<const int16_t*>(buf)); lens.push_back(ns); any = true; }
             in[k].samples += ns;
             in[k].ncarry = have - ns * 4;
             memcpy(in[k].carry, buf + ns * 4, in[k].ncarry);
-            any = true;
+            if (ended) {
+                in[k].eof = true;
+                --open_streams;
+                pending_flush.push_back(k);
+                any = true;
+            }
         }
         if (!ids.empty() && opv_push_iq_batch(ctx, (int)ids.size(), ids.data(), ptrs.data(), lens.data()) < 0) {
             fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error());
             return 2;
         }
+        for (int k : pending_flush)
+            if (opv_flush(ctx, k) < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
+        pending_flush.clear();
         if (any && drain() < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
     }
     if (drain() < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }

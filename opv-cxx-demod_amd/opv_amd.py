@@ -42,12 +42,12 @@ class OpvError(RuntimeError):
 
 class Cfg(C.Structure):
     _fields_ = [("streaming", C.c_int32), ("have_init_offset", C.c_int32), ("init_offset_hz", C.c_double),
-                ("afc_alpha", C.c_double), ("device", C.c_int32), ("keep_soft", C.c_int32),
+                ("afc_alpha", C.c_double), ("device", C.c_int32), ("reserved0", C.c_int32),
                 ("max_samples", C.c_uint64)]
 
 
 class FrameMeta(C.Structure):
-    _fields_ = [("viterbi_metric", C.c_int32), ("reserved", C.c_int32), ("sync_quality", C.c_double),
+    _fields_ = [("viterbi_metric", C.c_int32), ("sync_ok", C.c_int32), ("sync_quality", C.c_double),
                 ("release_symbol", C.c_uint64), ("payload_symbol", C.c_uint64)]
 
 
@@ -56,12 +56,13 @@ class StreamState(C.Structure):
                 ("mu", C.c_double), ("total_symbols", C.c_uint64), ("total_samples", C.c_uint64),
                 ("chunk_origin", C.c_uint64), ("sync_state", C.c_int32), ("frames_released", C.c_int32),
                 ("frames_decoded", C.c_int32), ("frames_perfect", C.c_int32), ("n_chunks", C.c_int32),
-                ("flushed", C.c_int32)]
+                ("flushed", C.c_int32), ("events_dropped", C.c_uint32), ("edge_ties", C.c_uint32),
+                ("stalled", C.c_int32), ("offset_ties", C.c_int32)]
 
 
 EVENT_DTYPE = np.dtype(
     [("kind", "<i4"), ("count", "<i4"), ("sym_idx", "<u8"), ("corr", "<f8"), ("raw", "<f8")], align=True)
-META_DTYPE = np.dtype([("viterbi_metric", "<i4"), ("reserved", "<i4"), ("sync_quality", "<f8"),
+META_DTYPE = np.dtype([("viterbi_metric", "<i4"), ("sync_ok", "<i4"), ("sync_quality", "<f8"),
                        ("release_symbol", "<u8"), ("payload_symbol", "<u8")], align=True)
 
 
@@ -168,7 +169,7 @@ class Demod:
                  device=0):
         self.n_streams = n_streams
         self.cfg = Cfg(int(streaming), int(init_offset is not None), float(init_offset or 0.0), afc_alpha,
-                       device, 1, int(max_samples))
+                       device, 0, int(max_samples))
         self.h = C.c_void_p()
         _chk(lib().opv_create(C.byref(self.h), n_streams, C.byref(self.cfg)))
         if os.environ.get("OPV_FRONTEND"):      # dev switch: run everything on one mapping (0 / 1 / 4)

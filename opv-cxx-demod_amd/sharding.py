@@ -24,6 +24,9 @@ def gather_frames(frames, counts, dst=0):
     if world == 1:
         return frames.unsqueeze(0), counts.unsqueeze(0)
     rank = dist.get_rank()
+    if dist.get_backend() == "gloo" and frames.is_cuda:
+        # gloo gathers host tensors only (the world-size-2-on-one-GPU test; RCCL refuses two ranks on one device)
+        frames, counts = frames.cpu(), counts.cpu()
     fl = [torch.empty_like(frames) for _ in range(world)] if rank == dst else None
     cl = [torch.empty_like(counts) for _ in range(world)] if rank == dst else None
     dist.gather(frames, fl, dst=dst)

@@ -450,3 +450,47 @@ def resample_clock(iq, ppm):
     out[0::2] = np.clip(np.rint(y.real), -32768, 32767).astype(np.int16)
     out[1::2] = np.clip(np.rint(y.imag), -32768, 32767).astype(np.int16)
     return out
+
+
+def channel_model(iq, gain=1.0, f0_hz=0.0, sigma=0.0, seed=0):
+    """CPU model of the product's device channel tool (csrc/k_channel.hip), operation for
+    operation: rotation by exp(j 2 pi f0 n / Fs) with the phase reduced in cycles, gain, counter-based AWGN
+    (splitmix64 finaliser keyed by seed ^ n * 0xD1342543DE82EF95 -> two 24-bit uniforms -> float32 Box-Muller),
+    round to nearest even, clip. The integer part (hash, uniforms) is exact; the transcendental part uses numpy's
+    float32 log / sincos and float64 sincos, which may differ from the device's by an ulp, i.e. the int16 result
+    may differ by one LSB where a value sits within ~1e-4 LSB of a rounding boundary (the GPU test counts them).
+    This pins what bench.py's and the BER curve's inputs ARE, off-device."""
+    iq = _iq(iq)
+    n = np.arange(iq.size // 2, dtype=np.uint64)
+    t = (f0_hz / 2168000.0) * n.astype(np.float64)
+    t = t - np.rint(t)
+    sn, cs = np.sin(2.0 * np.pi * t), np.cos(2.0 * np.pi * t)
+    # exact values at the points where sincospi is exact (the reduced phase is a multiple of 1/4 cycle)
+    q = np.rint(t * 4.0)
+    on = (t * 4.0 == q)
+    if on.any():
+        qi = q[on].astype(np.int64) % 4
+        sn[on] = np.array([0.0, 1.0, 0.0, -1.0])[qi]
+        cs[on] = np.array([1.0, 0.0, -1.0, 0.0])[qi]
+    xr = gain * iq[0::2].astype(np.float64)
+    xi = gain * iq[1::2].astype(np.float64)
+    yr = xr * cs - xi * sn
+    yi = xr * sn + xi * cs
+    if sigma > 0.0:
+        with np.errstate(over="ignore"):
+            z = (np.uint64(seed) ^ (n * np.uint64(0xD1342543DE82EF95))) + np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            h = z ^ (z >> np.uint64(31))
+        f32 = np.float32
+        u1 = ((h >> np.uint64(40)).astype(np.uint32).astype(f32) + f32(0.5)) * f32(1.0 / 16777216.0)
+        u2 = (((h >> np.uint64(8)) & np.uint64(0xFFFFFF)).astype(np.uint32).astype(f32) + f32(0.5)) * f32(1.0 / 16777216.0)
+        rad = np.sqrt(f32(-2.0) * np.log(u1))
+        a = (f32(2.0) * u2).astype(np.float64) * np.pi        # sincospif(2 u2): evaluated in double, rounded to float32
+        s2, c2 = np.sin(a).astype(f32), np.cos(a).astype(f32)
+        yr = yr + sigma * (rad * c2).astype(np.float64)
+        yi = yi + sigma * (rad * s2).astype(np.float64)
+    out = np.empty(iq.size, np.int16)
+    out[0::2] = np.clip(np.rint(yr), -32768, 32767).astype(np.int16)
+    out[1::2] = np.clip(np.rint(yi), -32768, 32767).astype(np.int16)
+    return out

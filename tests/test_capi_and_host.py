@@ -32,13 +32,32 @@ def test_library_exports_every_declared_symbol(amd):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/opv_demod.h but not exported"
     assert sorted(amd.EXPORTS) == names, "opv_amd.EXPORTS out of sync with the header"
-    assert L.opv_abi_version() == 1
+    assert L.opv_abi_version() == 2
 
 
-def test_struct_layouts_match_header(amd):
-    # sizes the C side static_asserts / documents: opv_event 32 B, opv_frame_meta 32 B
-    assert amd.EVENT_DTYPE.itemsize == 32 and amd.META_DTYPE.itemsize == 32
-    assert C.sizeof(amd.Cfg) == 40 and C.sizeof(amd.StreamState) == 80
+def test_struct_layouts_match_header(amd, tmp_path):
+    """sizes and field offsets of the ctypes / numpy mirrors against what gcc makes of include/opv_demod.h"""
+    import subprocess
+    fields = {"opv_cfg": [f[0] for f in amd.Cfg._fields_], "opv_stream_state": [f[0] for f in amd.StreamState._fields_],
+              "opv_frame_meta": list(amd.META_DTYPE.names), "opv_event": list(amd.EVENT_DTYPE.names)}
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT / "include" / "opv_demod.h"}"', "int main(void){"]
+    for st, fs in fields.items():
+        src.append(f'printf("{st} %zu\\n", sizeof({st}));')
+        src += [f'printf("{st}.{f} %zu\\n", offsetof({st}, {f}));' for f in fs]
+    src.append("return 0;}")
+    (tmp_path / "l.c").write_text("\n".join(src))
+    subprocess.run(["gcc", "-o", str(tmp_path / "l"), str(tmp_path / "l.c")], check=True)
+    got = dict(ln.split() for ln in subprocess.run([str(tmp_path / "l")], capture_output=True, text=True, check=True).stdout.splitlines())
+    assert int(got["opv_cfg"]) == C.sizeof(amd.Cfg) and int(got["opv_stream_state"]) == C.sizeof(amd.StreamState)
+    assert int(got["opv_frame_meta"]) == amd.META_DTYPE.itemsize == 32 and int(got["opv_event"]) == amd.EVENT_DTYPE.itemsize == 32
+    for f in fields["opv_cfg"]:
+        assert int(got[f"opv_cfg.{f}"]) == getattr(amd.Cfg, f).offset, f
+    for f in fields["opv_stream_state"]:
+        assert int(got[f"opv_stream_state.{f}"]) == getattr(amd.StreamState, f).offset, f
+    for f in fields["opv_frame_meta"]:
+        assert int(got[f"opv_frame_meta.{f}"]) == amd.META_DTYPE.fields[f][1], f
+    for f in fields["opv_event"]:
+        assert int(got[f"opv_event.{f}"]) == amd.EVENT_DTYPE.fields[f][1], f
 
 
 def test_no_gpu_means_loud_failure_not_fallback(amd):

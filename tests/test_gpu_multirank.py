@@ -1,0 +1,125 @@
+"""GPU tests of BASELINE configs[4]'s shape: the REAL pipeline under world_size > 1, and a 512-stream context.
+
+RCCL refuses two ranks on one device, so on a one-GPU box the two ranks of the first test share cuda:0 and
+rendezvous over gloo (sharding.gather_frames moves the library's device views through host memory for gloo);
+on the 8-GPU node the same code runs under "nccl" (bench.py). Every GLOBAL stream's frames, Viterbi metrics and
+sync positions are checked against the oracle run on that stream's own bytes."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _rank_main(rank, world, port, per_rank, n_frames, ebn0, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_opv_amd, load_pkg_module
+    from oracle_lib import Oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    amd, sharding, workload = load_opv_amd(), load_pkg_module("sharding"), load_pkg_module("workload")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    mine = sharding.stream_range(rank, world, world * per_rank)
+    n = amd.lib().opv_tx_modulated_samples(n_frames)
+    dm = amd.Demod(per_rank, max_samples=n + 64, streaming=True, device=0)
+    d_iq, tx, n = workload.generate(amd, dm, torch, dev, mine, n_frames, ebn0)
+    for k in range(per_rank):
+        dm.attach(k, d_iq[k].data_ptr(), n, eof=True)
+    dm.process()
+    dm.sync()
+    frames_view, counts_view = workload.frame_views(dm, torch, dev)
+    # the checker's side of the same shard: oracle on this rank's own bytes, gathered the same way
+    o = Oracle()
+    cap = frames_view.shape[1]
+    exp_frames = torch.zeros((per_rank, cap, 134), dtype=torch.uint8)
+    exp_counts = torch.zeros((per_rank,), dtype=torch.int32)
+    exp_meta = torch.zeros((per_rank, cap, 2), dtype=torch.int64)
+    got_meta = torch.zeros((per_rank, cap, 2), dtype=torch.int64)
+    host_iq = d_iq.cpu().numpy()
+    for k in range(per_rank):
+        e = o.receive(host_iq[k], streaming=True, want_soft=False)
+        nf = len(e["frames"])
+        exp_counts[k] = nf
+        exp_frames[k, :nf] = torch.from_numpy(e["frames"])
+        exp_meta[k, :nf, 0] = torch.from_numpy(e["metrics"].astype(np.int64))
+        exp_meta[k, :nf, 1] = torch.from_numpy(e["frame_sym"].astype(np.int64))
+        fr, meta = dm.pop_frames(k)
+        got_meta[k, :len(fr), 0] = torch.from_numpy(meta["viterbi_metric"].astype(np.int64))
+        got_meta[k, :len(fr), 1] = torch.from_numpy(meta["release_symbol"].astype(np.int64))
+    fa, ca = sharding.gather_frames(frames_view, counts_view, dst=0)          # the product's gather (device views)
+    ea, eca = sharding.gather_frames(exp_frames, exp_counts, dst=0)
+    ml = [torch.empty_like(got_meta) for _ in range(world)] if rank == 0 else None
+    el = [torch.empty_like(exp_meta) for _ in range(world)] if rank == 0 else None
+    dist.gather(got_meta, ml, dst=0)
+    dist.gather(exp_meta, el, dst=0)
+    if rank == 0:
+        got, exp = sharding.flatten_global(fa, ca), sharding.flatten_global(ea, eca)
+        ok = len(got) == world * per_rank and bool((ca == eca).all())
+        n_frames_total = 0
+        for g in range(world * per_rank):
+            ok &= bool(torch.equal(got[g].cpu(), exp[g]))
+            n_frames_total += len(got[g])
+        ok &= bool(torch.equal(torch.stack(ml), torch.stack(el)))
+        q.put((bool(ok), n_frames_total))
+    dm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_real_pipeline_every_global_stream_vs_oracle():
+    """two processes, each opv_process on its contiguous shard of 8 streams (16 global streams x 12 frames,
+    16 dB, f0 -1500..-786 Hz), frames gathered to rank 0 by sharding.gather_frames"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, 8, 12, 16.0, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    ok, nfr = q.get(timeout=10)
+    assert ok is True
+    assert nfr >= 16 * 11, nfr
+
+
+def test_512_stream_context_vs_oracle():
+    """configs[4]'s stream count in one context: 512 streams (8 shards of 64, global ids 0..511) x 3 frames,
+    Eb/N0 16 dB, every stream against the oracle (frames, metrics, sync positions, tracker lines, offset estimate)."""
+    import torch
+    from __graft_entry__ import load_opv_amd, load_pkg_module
+    from oracle_lib import Oracle
+    from test_gpu_parity import events_match
+    amd, workload = load_opv_amd(), load_pkg_module("workload")
+    dev = torch.device("cuda", 0)
+    S, F = 512, 3
+    n = amd.lib().opv_tx_modulated_samples(F)
+    dm = amd.Demod(S, max_samples=n + 64, streaming=True)
+    d_iq, tx, n = workload.generate(amd, dm, torch, dev, range(S), F, 16.0)
+    for k in range(S):
+        dm.attach(k, d_iq[k].data_ptr(), n, eof=True)
+    dm.process()
+    dm.sync()
+    host = d_iq.cpu().numpy()
+    o = Oracle()
+    total = 0
+    for k in range(S):
+        e = o.receive(host[k], streaming=True, want_soft=False)
+        fr, meta = dm.pop_frames(k)
+        assert np.array_equal(fr, e["frames"]), k
+        assert np.array_equal(meta["viterbi_metric"], e["metrics"]) and np.array_equal(meta["release_symbol"], e["frame_sym"]), k
+        events_match(amd, dm.pop_events(k), e["events"])
+        assert dm.state(k).est_offset_hz == e["est_offset"], k
+        total += len(fr)
+    assert total >= S * (F - 1)
+    dm.close()
