@@ -66,7 +66,7 @@ struct DecodeTaps {
 };
 
 // The whole FrameDecoder::decode for one frame, executed by one wave.
-__device__ inline void decode_one(const double* __restrict__ soft, uint32_t first, uint32_t mask,
+__device__ __forceinline__ void decode_one(const double* __restrict__ soft, uint32_t first, uint32_t mask,
                                   uint8_t* __restrict__ out,
                                   int32_t* __restrict__ metric_out, int8_t* tq, int8_t* td, uint8_t* tb,
                                   unsigned char* lds) {
@@ -133,13 +133,23 @@ __device__ inline void decode_one(const double* __restrict__ soft, uint32_t firs
     }
     int metric = (lane == 0) ? 0 : 0x3FFFFFF0;                   // ref :805-806
     const uint16_t* s_d2 = reinterpret_cast<const uint16_t*>(s_d);
-    auto acs = [&](auto phase_tag, int t) {
-        constexpr int PH = decltype(phase_tag)::value;
+    // The step's inputs and outputs are wave-uniform, and fetching / storing them one step at a time cost more
+    // issue slots than the add-compare-select itself (an LDS read + wait + v_readfirstlane to get the symbol pair,
+    // an exec-masked 64-bit LDS store by lane 0 for the decision word: 17 of 27 instructions per step). So the
+    // trellis runs in blocks of 48 steps (a multiple of the six phases): lane l fetches the symbol pair of step
+    // tb + l ONCE (one ds_read_u16 for the block), each step takes its pair with v_readlane and leaves its decision
+    // word in lane (t - tb) of a VGPR pair with two v_writelane, and the 48 words are stored by ONE ds_write_b64.
+    // The six butterfly masks live in SGPR pairs so that the word is three 64-bit scalar operations.
+    unsigned long long kmask[6] = {0xAAAAAAAAAAAAAAAAull, 0xCCCCCCCCCCCCCCCCull, 0xF0F0F0F0F0F0F0F0ull,
+                                   0xFF00FF00FF00FF00ull, 0xFFFF0000FFFF0000ull, 0xFFFFFFFF00000000ull};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) asm volatile("" : "+s"(kmask[k]));   // opaque: keeps them in SGPR pairs, 64-bit ops
+    int pairs = 0, dlo = 0, dhi = 0;
+    auto acs = [&](auto slot_tag) {                               // SLOT = t - tb: the lane that holds this step's pair / word
+        constexpr int SLOT = decltype(slot_tag)::value;
+        constexpr int PH = SLOT % 6;                              // blocks start on a multiple of six steps
         constexpr int K = (5 - PH + 6) % 6;
-        constexpr unsigned long long kB0 = K == 0 ? 0xAAAAAAAAAAAAAAAAull : K == 1 ? 0xCCCCCCCCCCCCCCCCull
-                                         : K == 2 ? 0xF0F0F0F0F0F0F0F0ull : K == 3 ? 0xFF00FF00FF00FF00ull
-                                         : K == 4 ? 0xFFFF0000FFFF0000ull : 0xFFFFFFFF00000000ull;
-        const unsigned pair = (unsigned)__builtin_amdgcn_readfirstlane((int)s_d2[t]);  // sg1 | sg2<<8, wave-uniform
+        const unsigned pair = (unsigned)__builtin_amdgcn_readlane(pairs, SLOT);   // sg1 | sg2<<8, wave-uniform
         const int sg1 = (int)(pair & 0xFF), sg2 = (int)(pair >> 8);
         const int b1 = m1c[PH] ^ sg1, c = m2c[PH] ^ sg2;         // ref :823-824
         int mp;                                                   // metric held by lane ^ (1 << K)
@@ -160,25 +170,34 @@ __device__ inline void decode_one(const double* __restrict__ soft, uint32_t firs
         const int oth = mp + b1 + (7 - c);
         const unsigned long long gt = __ballot(own > oth), lt = __ballot(own < oth);
         metric = own < oth ? own : oth;
-        const unsigned long long word = (gt & ~kB0) | (lt & kB0);  // 1 = upper predecessor taken (:829-831)
-        if (lane == 0) s_dec[t] = word;
+        const unsigned long long word = (gt & ~kmask[K]) | (lt & kmask[K]);  // 1 = upper predecessor taken (:829-831)
+        // (no clang builtin for v_writelane on this toolchain; the lane select is an inline constant, so the one
+        // scalar operand the instruction may take is the data)
+        int wl = dlo, wh = dhi;                                   // (locals: asm operands cannot name captures of a generic lambda)
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(wl) : "s"((unsigned)word), "n"(SLOT));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(wh) : "s"((unsigned)(word >> 32)), "n"(SLOT));
+        dlo = wl; dhi = wh;
     };
-    {
-        int t = 0;
-        for (; t + 6 <= OPV_FBITS; t += 6) {
-            acs(std::integral_constant<int, 0>{}, t);
-            acs(std::integral_constant<int, 1>{}, t + 1);
-            acs(std::integral_constant<int, 2>{}, t + 2);
-            acs(std::integral_constant<int, 3>{}, t + 3);
-            acs(std::integral_constant<int, 4>{}, t + 4);
-            acs(std::integral_constant<int, 5>{}, t + 5);
-        }
-        static_assert(OPV_FBITS % 6 == 4, "tail below handles four steps");
-        acs(std::integral_constant<int, 0>{}, t);
-        acs(std::integral_constant<int, 1>{}, t + 1);
-        acs(std::integral_constant<int, 2>{}, t + 2);
-        acs(std::integral_constant<int, 3>{}, t + 3);
+#define OPV_ACS6(G)                                                                                            \
+    acs(std::integral_constant<int, (G)>{}); acs(std::integral_constant<int, (G) + 1>{});                      \
+    acs(std::integral_constant<int, (G) + 2>{}); acs(std::integral_constant<int, (G) + 3>{});                  \
+    acs(std::integral_constant<int, (G) + 4>{}); acs(std::integral_constant<int, (G) + 5>{})
+    constexpr int kBlk = 48;
+    static_assert(kBlk % 6 == 0 && OPV_FBITS % kBlk == 16, "22 full blocks and a tail of 16 steps (6 + 6 + 4)");
+    for (int tb = 0; tb + kBlk <= OPV_FBITS; tb += kBlk) {
+        pairs = (int)s_d2[tb + (lane < kBlk ? lane : 0)];
+        OPV_ACS6(0); OPV_ACS6(6); OPV_ACS6(12); OPV_ACS6(18); OPV_ACS6(24); OPV_ACS6(30); OPV_ACS6(36); OPV_ACS6(42);
+        if (lane < kBlk) s_dec[tb + lane] = ((unsigned long long)(unsigned)dhi << 32) | (unsigned)dlo;
     }
+    {
+        constexpr int tb = OPV_FBITS - 16;
+        pairs = (int)s_d2[tb + (lane & 15)];
+        OPV_ACS6(0); OPV_ACS6(6);
+        acs(std::integral_constant<int, 12>{}); acs(std::integral_constant<int, 13>{});
+        acs(std::integral_constant<int, 14>{}); acs(std::integral_constant<int, 15>{});
+        if (lane < 16) s_dec[tb + lane] = ((unsigned long long)(unsigned)dhi << 32) | (unsigned)dlo;
+    }
+#undef OPV_ACS6
     __syncthreads();
 
     // ---- best end state: first minimum in STATE order (ref :835-837) ---------------------------

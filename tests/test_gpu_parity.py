@@ -177,12 +177,15 @@ def test_offset_search_near_tie_guard(amd, oracle, iq10):
     and re-evaluate the contenders in the reference's order of operations - and then return the oracle's estimate."""
     rng = np.random.default_rng(2024)
     caps = []
-    x = iq10[: 2 * 86720].copy(); x[1::2] = 0; caps.append(x)                       # I branch of the MSK capture
-    x = impair(iq10, amp=3000.0, f0_hz=900.0, ebn0_db=9.0, seed=5)[: 2 * 86720].copy(); x[1::2] = 0; caps.append(x)
-    for amp in (50, 3000, 30000):
-        x = np.zeros(2 * 86720, np.int16); x[0::2] = np.clip(np.rint(rng.standard_normal(86720) * amp), -32768, 32767); caps.append(x)
-    x = np.zeros(2 * 86720, np.int16); x[0::2] = 12345; caps.append(x)              # DC
-    x = np.zeros(2 * 86720, np.int16); x[0::2] = np.rint(9000 * np.cos(2 * np.pi * 14100.0 * np.arange(86720) / 2168000.0)); caps.append(x)
+    t = np.arange(86720)
+    # real tones well outside the +/-13.55 kHz pair: two window main lobes 2 x 20..33 kHz apart add up to a landscape
+    # that is convex at o = 0, so its maximum is the tied pair of edge candidates -1500 / +1500
+    for f_hz, amp in ((33550.0, 9000.0), (36000.0, 20000.0), (42000.0, 3000.0), (47000.0, 12000.0)):
+        x = np.zeros(2 * 86720, np.int16); x[0::2] = np.rint(amp * np.cos(2 * np.pi * f_hz * t / 2168000.0 + 0.3)); caps.append(x)
+    x = np.zeros(2 * 86720, np.int16); x[0::2] = np.rint(8000 * np.cos(2 * np.pi * 33550.0 * t / 2168000.0) + 300 * rng.standard_normal(86720)); caps.append(x)
+    x = np.zeros(2 * 86720, np.int16); x[0::2] = np.clip(np.rint(rng.standard_normal(86720) * 50), -32768, 32767); caps.append(x)   # real noise
+    x = iq10[: 2 * 86720].copy(); x[1::2] = 0; caps.append(x)                       # I branch of the MSK capture: peak at 0, no tie
+    x = np.zeros(2 * 86720, np.int16); x[0::2] = 12345; caps.append(x)              # DC: peak at 0, no tie
     d = amd.Demod(len(caps), max_samples=86720 + 64, streaming=True)
     got = d.receive(caps)
     n_guarded = 0
@@ -563,14 +566,15 @@ def test_config2_full_size_offset_awgn(amd, oracle, f0, ebn0):
 def test_frames_only_consumer_and_back_pressure(amd, oracle, iq100):
     """What opv-modem does with its child: it reads FRAMES and sends the tracker lines to /dev/null. A receiver
     that never calls opv_pop_events must run forever: the event log is lossy (most recent cap_events lines, the
-    rest counted in events_dropped). Here 100 frames go through an 8-chunk staging buffer (cap_events = 112,
-    ~200 tracker lines), frames popped every round, events never - then the retained tail of the log must be the
+    rest counted in events_dropped). Here 100 frames go through a 3-chunk staging buffer (7 frame slots, 92 event
+    slots; 102 tracker lines), frames popped every round, events never - then the retained tail of the log must be the
     oracle's last lines. Second half: a consumer that stops popping FRAMES gets back-pressure, not data loss: the
     stream pauses (state.stalled), pushes are refused with OPV_ECAPACITY once the staging buffer is full, and
     after the pops it resumes where it stopped - every frame still equal to the oracle's."""
     x = iq100
     exp = oracle.receive(x, streaming=True)
-    cap = 8 * 86720
+    cap = 3 * 86720 + 8192
+    n_slots = 4 * (cap // (2168 * 38) + 4) + 64          # opv_create: cap_events = 4 cap_frames + 64
     d = amd.Demod(1, max_samples=cap, streaming=True)
     frames = []
     step = 2 * 86720
@@ -586,15 +590,15 @@ def test_frames_only_consumer_and_back_pressure(amd, oracle, iq100):
     st = d.state(0)
     assert st.stalled == 0
     n_ev = len(exp["events"])
-    assert n_ev > 112, n_ev
-    assert st.events_dropped == n_ev - 112, (st.events_dropped, n_ev)
+    assert n_ev > n_slots, (n_ev, n_slots)
+    assert st.events_dropped == n_ev - n_slots, (st.events_dropped, n_ev)
     tail = d.pop_events(0)
-    assert len(tail) == 112
-    events_match(amd, tail, exp["events"][-112:])
-    assert d.state(0).events_dropped == n_ev - 112
+    assert len(tail) == n_slots
+    events_match(amd, tail, exp["events"][-n_slots:])
+    assert d.state(0).events_dropped == n_ev - n_slots
     d.close()
 
-    # back-pressure: frames are never dropped. cap_frames of this context = 8*86720 / 82384 + 4 = 12
+    # back-pressure: frames are never dropped (this context holds 7 unpopped frames per stream)
     d = amd.Demod(1, max_samples=cap, streaming=True)
     got, refused, o = [], 0, 0
     stalled_seen = False
