@@ -53,20 +53,20 @@ enum {
 };
 
 /* Replaces the flag parsing of main() (src/opv-demod.cpp:944-974) for the flags that reach
- * the hot path: -s, -o <hz>, -a <alpha>. (-c/-p select the batch coherent demodulator, which has no
- * reproducible output to build to - DESIGN.md §7; -q/-r only affect host printing.) */
+ * the hot path: -s, -o <hz>, -a <alpha>, and -c / -p <hz> (the batch coherent demodulator :365-572, prefix parity
+ * only - its loop is chaotic); -q/-r only affect host printing. */
 typedef struct opv_cfg {
     int32_t streaming;        /* 1: -s chunked semantics (:995-1125); 0: batch (:1132-1216) */
     int32_t have_init_offset; /* -o given: skip the offset search in streaming mode (:1004,:1031) */
     double init_offset_hz;    /* -o value */
     double afc_alpha;         /* -a value; 0.001 if <= 0 is NOT substituted: pass 0.001 for the default (:945) */
     int32_t device;           /* HIP device ordinal */
-    int32_t reserved0;        /* ignored (was keep_soft in ABI 1): the soft-symbol log is the hand-over between the
-                                 front-end kernel and the tracker / frame decoder kernels, so it is always written
-                                 (8 B per symbol = 5 % on top of the 4 B per sample read) */
+    int32_t coherent;         /* -c: Costas-loop demodulator instead of the energy detector; honoured in batch mode only,
+                                 like the reference (:1144; with -s it merely changes the banner, :983-984,995) */
     uint64_t max_samples;     /* per-stream DEVICE BUFFER capacity in IQ samples (< 2^31). Pushed streams may be
                                  arbitrarily long: consumed samples / soft symbols are dropped when the buffer
                                  fills (>= ~3 chunks + the largest push is enough); an attached capture must fit */
+    double pll_bw_hz;         /* -p value (coherent mode, set_pll_bandwidth :551-558); the reference's default is 50 */
 } opv_cfg;
 
 /* Per decoded frame: what main() knows when it prints/writes a frame

@@ -243,12 +243,16 @@ static_assert(2 * OPV_CODED % 8 == 0 && 2 * OPV_CODED + 8 * OPV_FBITS <= 17152, 
 extern "C" __global__ __launch_bounds__(64) void k_frame_decode(OpvStream* __restrict__ streams, uint32_t per_stream) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kDecodeLds];
     OpvStream& st = streams[blockIdx.x / per_stream];
-    const uint32_t f = st.dec_from + blockIdx.x % per_stream;
-    if (f >= st.n_frames) return;
-    const uint32_t slot = f % st.cap_frames;  // frame records / frames / metrics are rings
-    const OpvFrameRec rec = st.frec[slot];
-    decode_one(st.soft, (uint32_t)rec.payload_sym, (uint32_t)(st.cap_soft - 1), st.frames + (size_t)slot * OPV_FB,
-               st.metrics + slot, nullptr, nullptr, nullptr, lds);
+    // per_stream is the host's ESTIMATE of the frames a stream releases in a round (from the samples it pushed); a
+    // stream that was held back by back-pressure releases its backlog in one round, so the workgroups stride on
+    const uint32_t n_frames = st.n_frames;
+    for (uint32_t f = st.dec_from + blockIdx.x % per_stream; f < n_frames; f += per_stream) {
+        const uint32_t slot = f % st.cap_frames;  // frame records / frames / metrics are rings
+        const OpvFrameRec rec = st.frec[slot];
+        decode_one(st.soft, (uint32_t)rec.payload_sym, (uint32_t)(st.cap_soft - 1), st.frames + (size_t)slot * OPV_FB,
+                   st.metrics + slot, nullptr, nullptr, nullptr, lds);
+        __syncthreads();                          // the next frame reuses this workgroup's LDS
+    }
 }
 
 // stand-alone decoder over caller-provided payloads (parity tap / opv_decode_payloads)

@@ -605,7 +605,9 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
 
             // ---- timing loop, soft log, next symbol's taps ------------------------------------------
             tf = clampd(fma(kc_beta, ted, tf), kc_ntfmax, kc_tfmax);  // beta (ref :118,:283-284)
-            const double adj = clampd(fma(kc_alpha, ted, tf), -2.0, 2.0);  // alpha (ref :117,:285-286)
+            // alpha (ref :117,:285). The reference then clamps to +/-2 (:286): |ted| < 1 (num = L - E, den = L + E + 1e-10,
+            // L, E >= 0) and |tf| <= 0.1, so |adj| <= 0.105 and that clamp can never act - it is not issued.
+            const double adj = fma(kc_alpha, ted, tf);
             pos += 40.0 + adj;                                      // ref :313
             fetch_addr(pos, false);                                 // pos >= 38 after any symbol
             *(gdouble*)(soft_base + my_soft_off) = soft;            // all lanes, same value and address

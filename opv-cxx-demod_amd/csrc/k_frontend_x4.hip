@@ -371,7 +371,7 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_x4(OpvStream* __
                 ted = fma(fma(-den, ted, num), iden, ted);
                 // ---- timing loop (ref :283-286, :313) ------------------------------------------------
                 tf = clampd(fma(0.00001, ted, tf), -0.1, 0.1);
-                const double adj = clampd(fma(0.005, ted, tf), -2.0, 2.0);
+                const double adj = fma(0.005, ted, tf);   // |adj| <= 0.105: the reference's clamp to +/-2 (:286) cannot act, see k_frontend.hip
                 const double pos_next = pos + (40.0 + adj);
                 if ((uint32_t)t == (iter & 3u)) { held = soft; held_off = soft_off; held_valid = true; }
                 // ---- AFC (ref :289-306): not on the first symbol of a call -------------------------------

@@ -17,6 +17,7 @@
 // L2/HBM while hunting, 192 B/frame when locked.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdint.h>
 
 #include "opv_device.h"
 
@@ -78,6 +79,7 @@ extern "C" __global__ __launch_bounds__(64) void k_sync_track(OpvStream* __restr
             f.quality = quality;
             f.sync_ok = sync_ok;
             f.pad = 0;
+            st.metrics[n_frames % st.cap_frames] = INT32_MIN;   // "released, not decoded yet" (the slot is a ring entry)
         }
         ++n_frames;
         collecting = 0;

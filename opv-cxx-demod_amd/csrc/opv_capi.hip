@@ -21,6 +21,7 @@ extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg, const doubl
 extern "C" __global__ void k_msk_frontend(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4(OpvStream*, OpvGlobalCfg, int);
+extern "C" __global__ void k_coherent_frontend(OpvStream*, double, double);
 extern "C" __global__ void k_sync_track(OpvStream*);
 extern "C" __global__ void k_frame_decode(OpvStream*, uint32_t);
 extern "C" __global__ void k_decode_payloads(const double*, uint32_t, uint8_t*, int32_t*, int8_t*, int8_t*, uint8_t*);
@@ -451,7 +452,10 @@ extern "C" int opv_process(opv_ctx* c) {
     // two waves per SIMD); four streams per wave issue 137 instead of 213 instructions per symbol and
     // stream, which only pays once there are more streams than the chip has wave slots for
     const bool x4 = c->frontend == 4 || (c->frontend == 0 && S >= kFrontendX4MinStreams);
-    if (x4) k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
+    if (c->cfg.coherent && !c->cfg.streaming) {           // -c, batch only (ref :1144-1161)
+        const double wn = c->cfg.pll_bw_hz * 2.0 * M_PI, zeta = 0.707, fsym = 2168000.0 / 40.0;   // set_pll_bandwidth (ref :551-558)
+        k_coherent_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, 2.0 * zeta * wn / fsym, wn * wn / (fsym * fsym));
+    } else if (x4) k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
     else if (S > kFrontendWg4MinStreams && S <= kFrontendWg4MaxStreams)
         k_msk_frontend_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);
     else k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g, S);

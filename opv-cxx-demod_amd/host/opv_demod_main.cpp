@@ -111,7 +111,7 @@ void print_frame(int num, const uint8_t* f, int metric, double sync) {
 
 struct Options {
     bool quiet = false, raw = false, coherent = false, streaming = false, have_off = false;
-    double afc = 0.001, off = 0.0, capacity_sec = 2.0;
+    double afc = 0.001, off = 0.0, capacity_sec = 2.0, pll_bw = 50.0;  // ref :946
     int device = 0;
 };
 
@@ -223,7 +223,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "-c")) o.coherent = true;
         else if (!strcmp(argv[i], "-s")) o.streaming = true;
         else if (!strcmp(argv[i], "-a") && i + 1 < argc) o.afc = atof(argv[++i]);
-        else if (!strcmp(argv[i], "-p") && i + 1 < argc) ++i;
+        else if (!strcmp(argv[i], "-p") && i + 1 < argc) o.pll_bw = atof(argv[++i]);
         else if (!strcmp(argv[i], "-o") && i + 1 < argc) { o.off = atof(argv[++i]); o.have_off = true; }
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) o.device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--capacity-sec") && i + 1 < argc) o.capacity_sec = atof(argv[++i]);
@@ -233,10 +233,10 @@ int main(int argc, char** argv) {
             fprintf(stderr, "  -q          Quiet mode\n");
             fprintf(stderr, "  -r          Raw output to stdout\n");
             fprintf(stderr, "  -s          Streaming mode (for live PlutoSDR input)\n");
-            fprintf(stderr, "  -c          Coherent mode (batch only in the reference; not provided here, see DESIGN.md)\n");
+            fprintf(stderr, "  -c          Coherent mode (Costas loop, ~3dB better; batch mode only)\n");
             fprintf(stderr, "  -a <bw>     AFC bandwidth (default: 0.001)\n");
             fprintf(stderr, "  -o <hz>     Initial frequency offset (streaming mode)\n");
-            fprintf(stderr, "  -p <hz>     PLL bandwidth (coherent only; ignored)\n");
+            fprintf(stderr, "  -p <hz>     PLL bandwidth for coherent mode (default: 50)\n");
             fprintf(stderr, "  --device <n>        HIP device ordinal (default 0)\n");
             fprintf(stderr, "  --capacity-sec <s>  device staging buffer in seconds of IQ (default 2; streams may be any length)\n");
             fprintf(stderr, "  -h          Help\n");
@@ -244,15 +244,9 @@ int main(int argc, char** argv) {
         }
     }
     // -c: the reference honours it in batch mode only (:1144); with -s it merely changes the banner
-    // (:983-984) and the non-coherent streaming path runs (:995-1125). The batch Costas loop itself is
-    // not provided: it never locks and its trajectory is chaotic (1e-15 rad -> O(1) within 5 frames,
-    // tests/test_oracle_golden.py::test_coherent_loop_is_chaotic), so no implementation that is not
-    // arithmetic-identical to the reference, libm included, can reproduce its output.
-    if (o.coherent && !o.streaming) {
-        fprintf(stderr, "opv-demod: batch coherent mode (-c) is not provided by the MI355X build (DESIGN.md §7); "
-                        "use the non-coherent default\n");
-        return 2;
-    }
+    // (:983-984) and the non-coherent streaming path runs (:995-1125). The batch Costas loop runs on the GPU too
+    // (csrc/k_coherent.hip); its trajectory is chaotic in the reference itself, so the output agrees with the
+    // reference's for the first ~2000 symbols only.
     if (!o.quiet) {  // ref :981-990
         fprintf(stderr, "╔═══════════════════════════════════════════════════════════════════╗\n");
         if (o.coherent) fprintf(stderr, "║       OPV MSK Demodulator with Costas Loop v1.0 (coherent)       ║\n");
@@ -268,6 +262,8 @@ int main(int argc, char** argv) {
     cfg.init_offset_hz = o.off;
     cfg.afc_alpha = o.afc;
     cfg.device = o.device;
+    cfg.coherent = o.coherent;
+    cfg.pll_bw_hz = o.pll_bw;
 
     std::vector<char> buf(1 << 18);
     size_t carry = 0;  // bytes of a partial sample at the end of a read
@@ -338,7 +334,8 @@ int main(int argc, char** argv) {
     opv_stream_state st;
     if (opv_get_state(ctx, 0, &st) < 0) return die("opv_get_state");
     if (!o.quiet) {
-        fprintf(stderr, "Estimated carrier offset: %.1f Hz\n", st.est_offset_hz);  // ref :1170
+        fprintf(stderr, "Estimated carrier offset: %.1f Hz\n", st.est_offset_hz);  // ref :1151 / :1170
+        if (o.coherent) fprintf(stderr, "PLL bandwidth: %.1f Hz\n", o.pll_bw);       // ref :1157
         fprintf(stderr, "Demodulated %llu symbols, final AFC offset: %.1f Hz\n\n", (unsigned long long)st.total_symbols, st.freq_offset_hz);
     }
     Sink sink{ctx, o};

@@ -96,6 +96,7 @@ int main(int argc, char** argv) {
     cfg.init_offset_hz = off;
     cfg.afc_alpha = afc;
     cfg.device = device;
+    cfg.pll_bw_hz = 50.0;
     cfg.max_samples = 8 * OPV_CHUNK_SAMPLES;  // staging buffer per stream; streams themselves are unbounded
     opv_ctx* ctx = nullptr;
     if (opv_create(&ctx, S, &cfg) < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }

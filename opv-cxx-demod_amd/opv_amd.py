@@ -42,8 +42,8 @@ class OpvError(RuntimeError):
 
 class Cfg(C.Structure):
     _fields_ = [("streaming", C.c_int32), ("have_init_offset", C.c_int32), ("init_offset_hz", C.c_double),
-                ("afc_alpha", C.c_double), ("device", C.c_int32), ("reserved0", C.c_int32),
-                ("max_samples", C.c_uint64)]
+                ("afc_alpha", C.c_double), ("device", C.c_int32), ("coherent", C.c_int32),
+                ("max_samples", C.c_uint64), ("pll_bw_hz", C.c_double)]
 
 
 class FrameMeta(C.Structure):
@@ -166,10 +166,10 @@ class Demod:
     MSKDemodulatorAFC + SyncTracker + FrameDecoder per stream)."""
 
     def __init__(self, n_streams=1, max_samples=1 << 22, streaming=True, init_offset=None, afc_alpha=0.001,
-                 device=0):
+                 device=0, coherent=False, pll_bw=50.0):
         self.n_streams = n_streams
         self.cfg = Cfg(int(streaming), int(init_offset is not None), float(init_offset or 0.0), afc_alpha,
-                       device, 0, int(max_samples))
+                       device, int(coherent), int(max_samples), float(pll_bw))
         self.h = C.c_void_p()
         _chk(lib().opv_create(C.byref(self.h), n_streams, C.byref(self.cfg)))
         if os.environ.get("OPV_FRONTEND"):      # dev switch: run everything on one mapping (0 / 1 / 4)

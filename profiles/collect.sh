@@ -4,10 +4,12 @@
 #   profiles/<tag>_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary
 #   profiles/<tag>_pmc_*.txt            per-kernel PMC sums (separate passes; HBM bytes per
 #                                       MI355X_MICROARCH.md §HBM: FETCH_SIZE x2 for wide reads)
+#   profiles/<tag>_traffic.json         HBM bytes per launch + issued instructions per symbol of k_msk_frontend,
+#                                       derived from those passes (read by bench.py for roofline.traffic / .issue)
 #   profiles/<tag>_bench.json           the bench line of the un-profiled run
 # Everything is written under gpurun_out/profiles_<tag>/ and merged back by gpurun; copy the
 # summaries into profiles/ afterwards (see profiles/README.md).
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/profiles_$TAG
 rm -rf $O; mkdir -p $O
@@ -30,4 +32,27 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_IN
   f=$(find $O/p$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && agg $f > $O/${TAG}_pmc_$i.txt
 done
-cat $O/${TAG}_bench.json; head -8 $O/${TAG}_kernel_stats.csv; cat $O/${TAG}_pmc_*.txt
+python3 - $O $TAG <<'PY'
+import json, re, sys
+O, TAG = sys.argv[1], sys.argv[2]
+def val(i, kernel, counter):
+    for ln in open(f"{O}/{TAG}_pmc_{i}.txt"):
+        f = ln.split()
+        if f and f[0] == kernel and f[1] == counter:
+            return float(re.search(r"per_dispatch=(\S+)", ln).group(1))
+    return None
+S, F = 64, 1000
+n_sym = S * 2168099.0                     # symbols one launch demodulates (86 724 000 samples per stream, ~40 per symbol)
+fetch, write = val(1, "k_msk_frontend", "FETCH_SIZE"), val(2, "k_msk_frontend", "WRITE_SIZE")
+ips = {k: round(val(3, "k_msk_frontend", c) / n_sym, 2) for k, c in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS"))}
+out = {"kernel": "k_msk_frontend", "workload": {"streams_per_gpu": S, "frames_per_stream": F, "ebn0": 16.0},
+       "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
+       "hbm_read_bytes_per_launch": fetch * 1024 * 2, "hbm_write_bytes_per_launch": write * 1024,
+       "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
+       "instr_per_symbol": ips, "wave_cycles_per_symbol": round(val(3, "k_msk_frontend", "SQ_WAVE_CYCLES") * 4 / n_sym, 1),
+       "correction": "gfx950: FETCH_SIZE counts wide (16 B/lane) coalesced reads at 1/2 -> x2 (MI355X_MICROARCH.md §HBM); WRITE_SIZE exact; units are KiB",
+       "source": f"profiles/{TAG}_pmc_1.txt (FETCH_SIZE pass), profiles/{TAG}_pmc_2.txt (WRITE_SIZE pass), profiles/{TAG}_pmc_3.txt (SQ_INSTS_*, SQ_WAVE_CYCLES x 4), rocprofv3 --pmc, separate passes, command: python3 bench.py --no-extras --steps 1 --warmup 0"}
+json.dump(out, open(f"{O}/{TAG}_traffic.json", "w"), indent=1)
+print(json.dumps(out))
+PY
+cat $O/${TAG}_bench.json | head -c 600; echo; head -8 $O/${TAG}_kernel_stats.csv; cat $O/${TAG}_pmc_*.txt
