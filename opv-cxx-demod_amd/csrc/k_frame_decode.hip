@@ -87,8 +87,15 @@ __device__ __forceinline__ void decode_one(const double* __restrict__ soft, uint
 
     // ---- scale = mean |soft|, summed in index order (ref :856-858) --------------------------
     double scale = 0.0;
+    {
+        const double2* s2 = reinterpret_cast<const double2*>(s_soft);   // 16-byte LDS reads (same address in every lane: a broadcast)
 #pragma unroll 8
-    for (int i = 0; i < OPV_CODED; ++i) scale += fabs(s_soft[i]);
+        for (int i = 0; i < OPV_CODED / 2; ++i) {
+            const double2 v = s2[i];
+            scale += fabs(v.x);                                          // strictly in index order, like the reference's loop
+            scale += fabs(v.y);
+        }
+    }
     scale /= (double)OPV_CODED;
     if (scale < 1e-10) {  // ref :859 — frame silently dropped
         if (lane == 0) *metric_out = -1;
@@ -213,23 +220,38 @@ __device__ __forceinline__ void decode_one(const double* __restrict__ soft, uint
     // in lane space: the decoded bit is bit k of the current lane, the predecessor's lane has that bit
     // replaced by the decision
     int cur = bl;
-    int k = (5 - (OPV_FBITS - 1) % 6 + 6) % 6;
-    for (int i = 0; i < OPV_FB; ++i) {
+    // 24 steps are four turns of the bit position k and three output bytes: inside such a group every step's k is a
+    // compile-time constant (shifts by immediates, no scalar bookkeeping). The bytes go to LDS still randomised; the
+    // LFSR table is applied by all lanes at once on the way out (a per-byte constant-memory load inside this serial
+    // walk would put a global-memory round trip on every eighth step).
+    constexpr int kK0 = (5 - (OPV_FBITS - 1) % 6 + 6) % 6;
+    auto trace_byte = [&](auto first_step_tag, int i) {
+        constexpr int S0 = decltype(first_step_tag)::value;
         unsigned byte = 0;
+        const int t0 = OPV_FBITS - 1 - 8 * i;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int t = OPV_FBITS - 1 - 8 * i - j;
+            const int k = (kK0 + S0 + j) % 6;                     // k(t-1) = k(t) + 1 mod 6
+            const int t = t0 - j;
             const unsigned b = (unsigned)(cur >> k) & 1u;         // bits[t] = s % 2 -> bit j of byte i
             byte |= b << j;
             if (tb && lane == 0) tb[t] = (uint8_t)b;
             const unsigned d = (unsigned)((s_dec[t] >> cur) & 1ull);
             cur ^= (int)((b ^ d) << k);
-            k = (k == 5) ? 0 : k + 1;                             // k(t-1) = k(t) + 1 mod 6
         }
-        if (lane == 0) s_out[i] = (uint8_t)(byte ^ kLfsr.b[i]);
+        if (lane == 0) s_out[i] = (uint8_t)byte;
+    };
+    static_assert(OPV_FB % 3 == 2, "44 groups of three bytes and a tail of two");
+    int i = 0;
+    for (; i + 3 <= OPV_FB; i += 3) {
+        trace_byte(std::integral_constant<int, 0>{}, i);
+        trace_byte(std::integral_constant<int, 8>{}, i + 1);
+        trace_byte(std::integral_constant<int, 16>{}, i + 2);
     }
+    trace_byte(std::integral_constant<int, 0>{}, i);
+    trace_byte(std::integral_constant<int, 8>{}, i + 1);
     __syncthreads();
-    for (int i = lane; i < OPV_FB; i += 64) out[i] = s_out[i];
+    for (int q = lane; q < OPV_FB; q += 64) out[q] = (uint8_t)(s_out[q] ^ kLfsr.b[q]);   // derandomise (ref :887-895)
     if (lane == 0) *metric_out = bm;
 }
 

@@ -106,3 +106,23 @@ def test_cli_binaries_built_and_usage(amd):
     assert r.returncode == 0 and b"-s" in r.stderr and b"-o <hz>" in r.stderr
     out = subprocess.run([str(b / "opv-mod"), "-S", "W5NYV", "-B", "1"], capture_output=True).stdout
     assert len(out) == (2168 * 40 + 4000) * 4
+
+
+def test_bench_starts_its_own_ranks_and_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2` from a bare shell (no launcher environment) must start two rank processes itself -
+    before anything touches a GPU - and report their failure: here there is no GPU, so each rank says so and exits 2
+    (the product has no CPU path), and so does the parent. A --gpus that disagrees with WORLD_SIZE is refused."""
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 2, p.stderr
+    assert p.stderr.count("no GPU visible") == 2, p.stderr
+    env["WORLD_SIZE"] = "4"
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 2 and "disagrees with WORLD_SIZE=4" in p.stderr
