@@ -51,7 +51,7 @@ constexpr uint32_t kBlock = 64;                     // samples per refill block 
 constexpr uint32_t kAheadMin = 544;                 // keep hi >= floor(pos) + this (56 reach + 4 symbols x 42 + 320)
 constexpr uint32_t kTabOff = 4 * kRowBytes;         // 17408
 constexpr uint32_t kTabRow = 10;
-constexpr uint32_t kLdsBytes = kTabOff + 33 * kTabRow * 8;  // 20048 <= 20480: eight workgroups per CU
+// LDS per workgroup: WPB x kTabOff + the atan table = 20 048 B for one wave (eight workgroups per CU), 72 272 B for four (two)
 static_assert(kTabOff % 16 == 0, "16-byte LDS alignment");
 
 typedef __attribute__((address_space(1))) double gdouble;
@@ -134,16 +134,20 @@ __device__ __noinline__ double2 silence_pd_x4(double dr, double di, double pa, d
 
 extern __constant__ double kOpvAtanTab[33][10];  // defined with k_frontend.hip (opv_atan2.h)
 
-extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_x4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
-                                                                    int n_streams) {
-    const int lane = threadIdx.x, row = lane >> 4, t = lane & 15;
-    const int sidx = (int)blockIdx.x * 4 + row;
+// WPB = wavefronts per workgroup (k_frontend.hip, msk_frontend_body: single-wave workgroups are placed without regard
+// to SIMDs, four waves of one workgroup always land on the four SIMDs of a CU). Waves share only the atan table.
+template <int WPB>
+__device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ streams, OpvGlobalCfg cfg, int n_streams) {
+    const int lane = threadIdx.x & 63, row = lane >> 4, t = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sidx = ((int)blockIdx.x * WPB + wave) * 4 + row;
     const bool have = sidx < n_streams;
     OpvStream& st = streams[have ? sidx : n_streams - 1];   // idle rows read a valid record and never write
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds[kLdsBytes];
-    double* atab = reinterpret_cast<double*>(lds + kTabOff);
-    for (int i = lane; i < 33 * (int)kTabRow; i += 64) atab[i] = (&kOpvAtanTab[0][0])[i];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[WPB * kTabOff + 33 * kTabRow * 8];
+    unsigned char* const lds = lds_all + wave * kTabOff;    // this wave's four rings
+    double* atab = reinterpret_cast<double*>(lds_all + WPB * kTabOff);
+    for (int i = threadIdx.x; i < 33 * (int)kTabRow; i += 64 * WPB) atab[i] = (&kOpvAtanTab[0][0])[i];
     const unsigned char* ring = lds + (uint32_t)row * kRowBytes;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const uint32_t ring_lds = lds_base + (uint32_t)row * kRowBytes;
@@ -438,4 +442,14 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_x4(OpvStream* __
         st.n_chunks = n_chunks; st.tail_done = tail_done; st.overflow = overflow;
         st.stalled = stalled; st.edge_ties = edge_ties;
     }
+}
+
+extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_x4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
+                                                                    int n_streams) {
+    msk_frontend_x4_body<1>(streams, cfg, n_streams);
+}
+// sixteen streams per workgroup: one wave per SIMD of a CU by construction
+extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_x4_wg4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
+                                                                        int n_streams) {
+    msk_frontend_x4_body<4>(streams, cfg, n_streams);
 }

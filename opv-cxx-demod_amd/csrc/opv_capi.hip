@@ -21,6 +21,7 @@ extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg, const doubl
 extern "C" __global__ void k_msk_frontend(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4(OpvStream*, OpvGlobalCfg, int);
+extern "C" __global__ void k_msk_frontend_x4_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_coherent_frontend(OpvStream*, double, double);
 extern "C" __global__ void k_sync_track(OpvStream*);
 extern "C" __global__ void k_frame_decode(OpvStream*, uint32_t);
@@ -50,6 +51,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 // one wave per stream, four of them per workgroup: from the stream count at which single-wave workgroups start to
 // double up on SIMDs (k_frontend.hip: msk_frontend_body) up to the count its two workgroups per CU (LDS) can hold at once
 constexpr int kFrontendWg4MinStreams = 512, kFrontendWg4MaxStreams = 2048;
+constexpr int kFrontendX4Wg4MaxStreams = 8192;   // 2048 waves = two 80 KB workgroups per CU; beyond that single-wave workgroups (20 KB)
 constexpr int kFrontendX4MinStreams = 8192;  // measured cross-over on MI355X (front-end alone 173 vs 112 GS/s there, 87 vs 109 at 4096)
 
 struct StreamIn {  // host -> device per-round update
@@ -455,7 +457,9 @@ extern "C" int opv_process(opv_ctx* c) {
     if (c->cfg.coherent && !c->cfg.streaming) {           // -c, batch only (ref :1144-1161)
         const double wn = c->cfg.pll_bw_hz * 2.0 * M_PI, zeta = 0.707, fsym = 2168000.0 / 40.0;   // set_pll_bandwidth (ref :551-558)
         k_coherent_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, 2.0 * zeta * wn / fsym, wn * wn / (fsym * fsym));
-    } else if (x4) k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
+    } else if (x4 && S <= kFrontendX4Wg4MaxStreams)        // up to two waves per SIMD: four waves (16 streams) per workgroup
+        k_msk_frontend_x4_wg4<<<(S + 15) / 16, 256, 0, c->stream>>>(c->d_streams, g, S);
+    else if (x4) k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
     else if (S > kFrontendWg4MinStreams && S <= kFrontendWg4MaxStreams)
         k_msk_frontend_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);
     else k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g, S);
