@@ -52,7 +52,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 // double up on SIMDs (k_frontend.hip: msk_frontend_body) up to the count its two workgroups per CU (LDS) can hold at once
 constexpr int kFrontendWg4MinStreams = 512, kFrontendWg4MaxStreams = 2048;
 constexpr int kFrontendX4Wg4MaxStreams = 8192;   // 2048 waves = two 80 KB workgroups per CU; beyond that single-wave workgroups (20 KB)
-constexpr int kFrontendX4MinStreams = 8192;  // measured cross-over on MI355X (front-end alone 173 vs 112 GS/s there, 87 vs 109 at 4096)
+constexpr int kFrontendX4MinStreams = 4096;      // measured cross-over on MI355X: front-end alone 118 vs 110 GS/s at 4096 streams, 130 vs 111 at 6144
 
 struct StreamIn {  // host -> device per-round update
     const int16_t* iq;
