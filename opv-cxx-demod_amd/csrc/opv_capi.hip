@@ -20,6 +20,7 @@
 extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg, const double*);
 extern "C" __global__ void k_msk_frontend(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_wg4(OpvStream*, OpvGlobalCfg, int);
+extern "C" __global__ void k_msk_frontend_dual(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_coherent_frontend(OpvStream*, double, double);
@@ -457,6 +458,8 @@ extern "C" int opv_process(opv_ctx* c) {
     if (c->cfg.coherent && !c->cfg.streaming) {           // -c, batch only (ref :1144-1161)
         const double wn = c->cfg.pll_bw_hz * 2.0 * M_PI, zeta = 0.707, fsym = 2168000.0 / 40.0;   // set_pll_bandwidth (ref :551-558)
         k_coherent_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, 2.0 * zeta * wn / fsym, wn * wn / (fsym * fsym));
+    } else if (c->frontend == -2) {                        // two waves per stream (opv_set_frontend(-2))
+        k_msk_frontend_dual<<<S, 128, 0, c->stream>>>(c->d_streams, g, S);
     } else if (x4 && S <= kFrontendX4Wg4MaxStreams)        // up to two waves per SIMD: four waves (16 streams) per workgroup
         k_msk_frontend_x4_wg4<<<(S + 15) / 16, 256, 0, c->stream>>>(c->d_streams, g, S);
     else if (x4) k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
@@ -479,8 +482,8 @@ extern "C" int opv_process(opv_ctx* c) {
 
 extern "C" int opv_set_frontend(opv_ctx* c, int streams_per_wave) {
     if (!c) return fail(OPV_EINVAL, "null context");
-    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4)
-        return fail(OPV_EINVAL, "opv_set_frontend: 0 (automatic), 1 or 4 streams per wave");
+    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4 && streams_per_wave != -2)
+        return fail(OPV_EINVAL, "opv_set_frontend: 0 (automatic), 1 or 4 streams per wave, -2 = two waves per stream");
     c->frontend = streams_per_wave;
     return OPV_OK;
 }
@@ -557,6 +560,7 @@ extern "C" long opv_pop_frames(opv_ctx* c, int s, uint8_t* out, size_t cap, opv_
     if (int r = check_stream(c, s)) return r;
     if (int r = c->refresh()) return r;
     const OpvStream& st = c->mirror[s];
+    if (st.overflow == 2) return fail(OPV_EHIP, "front-end: the two wavefronts of a stream lost each other (hand-over timed out)");
     if (st.overflow) return fail(OPV_EINVAL, "opv_cfg.max_samples too large for the soft-symbol ring (internal limit 2^28 symbols)");
     HostStream& h = c->hs[s];
     const uint32_t nf = st.n_frames;

@@ -44,13 +44,15 @@ RAW_FIELD = __import__("re").compile(r"raw=(-?\d+)\)")
 def events_match(amd, got_ev, exp_ev):
     """Tracker events: kind, symbol index and counters are integers -> exact. corr / raw are fp64
     sums of soft symbols, which agree with the reference to ~1e-14 relative, not bit for bit. The printed
-    lines must be IDENTICAL except for one field: `raw=%.0f` of the HUNTING->VERIFYING line (a 12-digit
-    number) may differ by ONE unit in its last printed digit when a .5 boundary falls between the two
-    values. Everything else in every line - including corr=%.3f - is compared as text. How many lines may
-    carry that difference follows from the values themselves: a rounding boundary falls between two numbers
-    d apart with probability d, so the expected count is sum |raw_got - raw_exp| over the printed lines
-    (~1e-3 per line at 16 dB, ~1e-2 at 6 dB where the soft symbols sit at the reference's own 2.5e-10
-    noise floor); the bound is that expectation plus four standard deviations, plus one."""
+    lines must be IDENTICAL except for one field: the integer printed by `raw=%.0f` in the HUNTING->VERIFYING
+    line (a 12-digit number: the signed sum of 24 soft symbols) may differ in its last place(s) - by at most
+    1 + 2e-11 |raw|, i.e. one unit for the 1e10-scale sums of the amplitude-2000 captures and a few units for
+    full-scale ones (soft symbols ~4e11, agreeing to ~3e-13 each). Everything else in every line - including
+    corr=%.3f - is compared as text. How many lines may carry a difference follows from the values themselves:
+    a rounding boundary falls between two numbers d apart with probability min(1, d), so the expected count is
+    the sum of that over the printed lines (~1e-3 per line at 16 dB / amplitude 2000, ~0.1 at 6 dB where the soft
+    symbols sit at the reference's own 2.5e-10 noise floor); the bound is that expectation plus four standard
+    deviations, plus one."""
     assert len(got_ev) == len(exp_ev), "number of tracker events differs"
     if len(exp_ev) == 0:
         return 0
@@ -68,10 +70,11 @@ def events_match(amd, got_ev, exp_ev):
         # the only licence: the raw= integer, off by one
         assert RAW_FIELD.sub("raw=#)", x) == RAW_FIELD.sub("raw=#)", y), f"tracker line differs outside raw=: {x!r} vs {y!r}"
         rx, ry = RAW_FIELD.search(x), RAW_FIELD.search(y)
-        assert rx and ry and abs(int(rx.group(1)) - int(ry.group(1))) == 1, f"raw= differs by more than its last digit: {x!r} vs {y!r}"
+        assert rx and ry and abs(int(rx.group(1)) - int(ry.group(1))) <= 1 + 2e-11 * abs(int(ry.group(1))), \
+            f"raw= differs by more than its last place: {x!r} vs {y!r}"
         ndiff += 1
     printed = exp_ev["kind"] == 1                       # only the HUNTING->VERIFYING line prints raw=
-    expect = float(np.sum(np.abs(got_ev["raw"][printed] - exp_ev["raw"][printed])))
+    expect = float(np.sum(np.minimum(1.0, np.abs(got_ev["raw"][printed] - exp_ev["raw"][printed]))))
     assert ndiff <= 1 + expect + 4.0 * np.sqrt(expect), \
         f"{ndiff} of {int(printed.sum())} raw= fields differ in the last digit, {expect:.2f} expected from the values"
     return ndiff
@@ -152,6 +155,25 @@ def test_afc_alpha_flag(amd, oracle, iq10):
     d = amd.Demod(1, max_samples=iq10.size // 2 + 64, streaming=True, afc_alpha=0.01)
     got = d.receive([iq10])[0]
     check_stream(amd, got, oracle.receive(iq10, streaming=True, afc_alpha=0.01), "-a 0.01")
+    d.close()
+
+
+def test_two_waves_per_stream_mapping_is_exact(amd, oracle, iq10, iq100):
+    """opv_set_frontend(-2): the timing loop and the AFC on two wavefronts that exchange pos / fo through LDS every
+    symbol (csrc/k_frontend_dual.hip; not selected automatically). Same bar as the other mappings: clean, offset + noise,
+    an out-of-range -o, ragged lengths, -s and batch, several streams in one context."""
+    caps = [iq10, impair(iq10, amp=3000.0, f0_hz=-1700.0, ebn0_db=9.0, seed=3), impair(iq100[: 2 * 40 * 86720], amp=2000.0, f0_hz=900.0, ebn0_db=14.0, seed=8),
+            iq10[: 2 * 123457], iq10[: 2 * 86719], np.zeros(2 * 90000, np.int16)]
+    for streaming in (True, False):
+        d = amd.Demod(len(caps), max_samples=max(c.size for c in caps) // 2 + 64, streaming=streaming)
+        d.set_frontend(-2)
+        got = d.receive(caps)
+        d.close()
+        for k, x in enumerate(caps):
+            check_stream(amd, got[k], oracle.receive(x, streaming=streaming), f"dual stream {k} streaming={streaming}")
+    d = amd.Demod(1, max_samples=iq10.size // 2 + 64, streaming=True, init_offset=150000.0, afc_alpha=0.01)
+    d.set_frontend(-2)
+    check_stream(amd, d.receive([iq10])[0], oracle.receive(iq10, streaming=True, init_offset=150000.0, afc_alpha=0.01), "dual -o 150000")
     d.close()
 
 
