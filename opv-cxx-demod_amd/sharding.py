@@ -20,9 +20,9 @@ def stream_range(rank, world, total_streams):
 def gather_frames(frames, counts, dst=0):
     """frames: [S, cap, 134] uint8, counts: [S] int32 (same shapes on every rank).
     Returns (frames_all [world, S, cap, 134], counts_all [world, S]) on dst, (None, None) elsewhere."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return frames.unsqueeze(0), counts.unsqueeze(0)
+    world = dist.get_world_size()      # (a one-rank group still goes through the collective: bench.py's OPV_BENCH_FORCE_DIST self-test)
     rank = dist.get_rank()
     if dist.get_backend() == "gloo" and frames.is_cuda:
         # gloo gathers host tensors only (the world-size-2-on-one-GPU test; RCCL refuses two ranks on one device)
