@@ -966,6 +966,25 @@ def test_host_cli_process_contract(amd, golden, iq10):
     assert "Demodulated 21780 symbols, final AFC offset: " in err                  # the reference's count (:462, :1173)
 
 
+def test_reference_makefile_targets_with_our_binaries():
+    """The reference's own (and only) tests, run on the drop-in binaries: `make test` (Makefile:23-25: opv-mod -S W5NYV
+    -B 5 | opv-demod -s, grep Station|Token|Summary) and `make test-raw` (Makefile:28-33: three hand-built frames through
+    opv-mod -R | opv-demod -s -r must come back byte for byte - the one byte-exact KAT the reference repo holds)."""
+    import subprocess
+    mod = str(ROOT / "opv-cxx-demod_amd" / "bin" / "opv-mod")
+    dem = str(ROOT / "opv-cxx-demod_amd" / "bin" / "opv-demod")
+    iq = subprocess.run([mod, "-S", "W5NYV", "-B", "5"], capture_output=True, timeout=120).stdout
+    p = subprocess.run([dem, "-s"], input=iq, capture_output=True, timeout=300)
+    err = p.stderr.decode()
+    assert p.returncode == 0
+    assert err.count("Station ID:  W5NYV") == 5 and err.count("Token:       0xBBAADD (default)") == 5
+    assert "Summary: 5 frames (5 perfect, 0 errors)" in err
+    frames = b"".join(bytes([0, 0, 3, 0x74, 0x26, 0x97, 0xBB, 0xAA, 0xDD] + [0] * 3 + [(i + j) & 0xFF for j in range(122)]) for i in range(3))
+    iq = subprocess.run([mod, "-R"], input=frames, capture_output=True, timeout=120).stdout
+    p = subprocess.run([dem, "-s", "-r"], input=iq, capture_output=True, timeout=300)
+    assert p.returncode == 0 and p.stdout == frames, "raw mode: the three frames did not come back byte for byte"
+
+
 @pytest.mark.parametrize("seed", [20261003 + k for k in range(int(os.environ.get("OPV_FUZZ_SEEDS", "1")))])
 def test_clock_rate_error_and_random_channels_fuzz(amd, oracle, iq10, iq100, seed):
     """Differential fuzz: 24 streams in one context, each with its own sample-clock error (the timing
