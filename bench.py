@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1000, help="frames per stream")
     ap.add_argument("--ebn0", type=float, default=16.0, help="dB; <=0 disables noise")
     ap.add_argument("--no-extras", action="store_true", help="skip configs[1], the sweep and the CPU baseline")
+    ap.add_argument("--no-big", action="store_true", help="skip the 512-stream x F-frame single-GPU run of the extras (178 GB of HBM)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -428,6 +429,41 @@ def main():
         tgt = [int(k.split("x")[0]) for k, v in sweep.items() if max(e["Msamples/s"] for e in v.values()) >= 21680.0]
         extras["streams_for_target"] = {"target_Msamples/s": 21680.0, "smallest_swept_stream_count_meeting_it": min(tgt) if tgt else None,
                                         "swept": sorted(int(k.split("x")[0]) for k in sweep)}
+        # BASELINE configs[4]'s whole workload (512 streams x F frames, 64 per GPU on eight of them) on THIS one GPU:
+        # the same generator, global stream ids 0..511, everything resident in HBM (178 GB at F = 1000), one launch.
+        if not args.no_big and S == 64:
+            try:
+                free_b, _tot = torch.cuda.mem_get_info()
+                need_b = 512 * n * 4 * 1.10 + (4 << 30)
+                if free_b < need_b:
+                    extras["configs4_workload_on_one_gpu"] = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, {need_b / 1e9:.0f} GB needed"}
+                else:
+                    big = amd.Demod(512, max_samples=n + 64, streaming=True, device=local_rank)
+                    d_big, tx_big, _n = workload.generate(amd, big, torch, dev, range(512), F, args.ebn0)
+                    big.enable_timing(True)
+                    for rep in range(2):
+                        big.reset()
+                        for k in range(512):
+                            big.attach(k, d_big[k].data_ptr(), n, eof=True)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        big.process()
+                        big.sync()
+                        t1 = time.perf_counter() - t0
+                    fv, cv = workload.frame_views(big, torch, dev)
+                    ok_counts = bool((cv == F).all().item())
+                    exp_b = torch.from_numpy(tx_big).to(dev)
+                    n_bad = int((fv[:, :F, :] != exp_b).any(dim=2).sum().item())
+                    extras["configs4_workload_on_one_gpu"] = {
+                        "streams": 512, "frames_per_stream": F, "iq_GB_in_hbm": round(512 * n * 4 / 1e9, 1),
+                        "Msamples/s": round(512 * n / t1 / 1e6, 1), "x_realtime": round(512 * n / t1 / 2.168e6, 0), "ms": round(t1 * 1e3, 2),
+                        "kernel_ms": {k: round(v, 3) for k, v in big.kernel_times().items()},
+                        "every_stream_released_all_frames": ok_counts, "frames_exact": 512 * F - n_bad, "frames_total": 512 * F}
+                    big.close()
+                    del d_big, fv, cv, exp_b
+                    torch.cuda.empty_cache()
+            except Exception as e:                       # an extra must never cost the bench line
+                extras["configs4_workload_on_one_gpu"] = {"error": repr(e)[:300]}
         out["extras"] = extras
         base = d_base.cpu().numpy()
         raw = base.tobytes()
