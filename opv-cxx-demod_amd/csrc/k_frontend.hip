@@ -610,6 +610,9 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             const double adj = fma(kc_alpha, ted, tf);
             pos += 40.0 + adj;                                      // ref :313
             fetch_addr(pos, false);                                 // pos >= 38 after any symbol
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_read();                                           // next symbol's taps requested as soon as their address exists
+            __builtin_amdgcn_sched_barrier(0);
             *(gdouble*)(soft_base + my_soft_off) = soft;            // all lanes, same value and address
             [[maybe_unused]] double pd_off = 0;
             if constexpr (!kFirst) {
@@ -617,11 +620,9 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 sx = mkd((dhi(cx) & (int)0x80000000) | 0x3ff00000, dlo(sx));
                 pd_off = fma(-sx, kc_halfpi, kc_halfpi);
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): table row landed; waited for here,
-                __builtin_amdgcn_sched_barrier(0);                  //   before the taps are requested
+                __builtin_amdgcn_s_waitcnt(0xC17F);                 // lgkmcnt(1): the table row landed (LDS returns in order; only
+                __builtin_amdgcn_sched_barrier(0);                  //   the tap read, the newest operation, may still be in flight)
             }
-            fetch_read();
-            __builtin_amdgcn_sched_barrier(0);
 
             // ---- AFC ------------------------------------------------------------------------------
             if constexpr (!kFirst) {
