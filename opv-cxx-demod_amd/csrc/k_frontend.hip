@@ -216,6 +216,37 @@ __device__ __noinline__ double2 silence_pd(double dr, double di, PrevSums prv, b
 
 #include "opv_atan2.h"  // kOpvAtanTab (constant-memory image of the table) + host reference routine
 
+// ---- two-waves-per-stream mapping (ROLE 1 / 2 of msk_frontend_body): hand-over slots behind the atan table -------
+constexpr uint32_t kXchgPos = 0;      // 2 x {double pos; uint32 tag; pad}: position of symbol `tag`, written by the timing wave
+constexpr uint32_t kXchgFo = 32;      // 2 x {double fo;  uint32 tag; pad}: frequency for symbol `tag`, written by the AFC wave
+constexpr uint32_t kXchgBytes = 64;
+constexpr uint32_t kPollLimit = 1u << 22;   // a wave that has polled this often gives up: nothing can hang
+
+// Wait until the {value, tag} slot at LDS address `a` carries `want`: one scalar loop (tag first, then the value - LDS
+// reads of a wave return in order, so a matching tag guarantees the value written before it).
+__device__ inline void role_await(uint32_t a, uint32_t want, double& v, uint32_t& timeouts) {
+    uint32_t got_v, got_s, cnt;
+    double val;
+    asm volatile(
+        "s_mov_b32 %[cnt], 0\n"
+        "1:\n\t"
+        "ds_read_b32 %[gv], %[a] offset:8\n\t"
+        "ds_read_b64 %[val], %[a]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[gs], %[gv]\n\t"
+        "s_cmp_eq_u32 %[gs], %[want]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_add_u32 %[cnt], %[cnt], 1\n\t"
+        "s_cmp_lt_u32 %[cnt], %[lim]\n\t"
+        "s_cbranch_scc1 1b\n"
+        "2:"
+        : [gv] "=&v"(got_v), [val] "=&v"(val), [gs] "=&s"(got_s), [cnt] "=&s"(cnt)
+        : [a] "v"(a), [want] "s"(want), [lim] "s"(kPollLimit)
+        : "memory", "scc");
+    timeouts |= (cnt >= kPollLimit) ? 1u : 0u;
+    v = val;
+}
+
 // WPB = wavefronts (= streams) per workgroup. One wave per workgroup is the natural shape, but the dispatcher
 // places single-wave workgroups without regard to SIMDs: with 1024 of them on the chip's 1024 SIMDs, 88 SIMDs
 // received two waves and 88 none (census from this kernel's own HW_ID tap, profiles/r02_placement_1024_streams.txt),
@@ -223,19 +254,29 @@ __device__ __noinline__ double2 silence_pd(double dr, double di, PrevSums prv, b
 // the kernel's duration. A 256-thread workgroup's four waves always land on the four SIMDs of one CU, so from 513
 // streams on the shim launches four streams per workgroup (k_msk_frontend_wg4). Waves of a workgroup share nothing
 // but the atan table.
-template <int WPB>
-__device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ streams, OpvGlobalCfg cfg, int n_streams) {
+// ROLE 0: the whole demodulator on one wave. ROLE 1 / 2: the two-waves-per-stream mapping (k_msk_frontend_dual) - wave T
+// (1) runs the timing loop, wave F (2) the AFC; both form the taps and the on-time sums (identical operations on identical
+// bits), every statement below that belongs to the other loop is compiled out, and at the end of a symbol T publishes
+// pos(k+1), F publishes fo(k+1); each waits for the other's number where it first needs it. Tile staging is T's; its
+// events keep one symbol more margin so that F, at most one symbol behind, never reads a tile that has not landed or has
+// been recycled. STATUS: exact (tests/test_gpu_parity.py::test_two_waves_per_stream_mapping_is_exact) but 6 % SLOWER than
+// ROLE 0 (1111 vs 1043 cycles per symbol at 64 streams): each wave's LDS round trips and cross-lane hazard slots are no
+// longer filled by the other loop's arithmetic, and the partner is waited for once per symbol. It is
+// never selected automatically (opv_set_frontend(ctx, -2)).
+template <int WPB, int ROLE>
+__device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ streams, OpvGlobalCfg cfg, int n_streams,
+                                                  unsigned char* lds_all) {
+    constexpr bool kT = ROLE != 2;       // this wave runs the timing loop (and stages the tiles)
+    constexpr bool kF = ROLE != 1;       // this wave runs the AFC (and logs the soft symbols)
+    constexpr bool kDual = ROLE != 0;
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int sidx = (int)blockIdx.x * WPB + wave;
+    const int wave = kDual ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int sidx = kDual ? (int)blockIdx.x : (int)blockIdx.x * WPB + wave;
     const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[WPB * kTabOff + 33 * kTabRow * 8];
-    unsigned char* const lds = lds_all + wave * kTabOff;      // this wave's ring + guard
+    unsigned char* const lds = lds_all + wave * kTabOff;      // this wave's ring + guard (shared by T and F)
     const unsigned char* ringb = lds;
-    double* atab = reinterpret_cast<double*>(lds_all + WPB * kTabOff);
-    for (int i = threadIdx.x; i < 33 * (int)kTabRow; i += 64 * WPB) atab[i] = (&kOpvAtanTab[0][0])[i];
-    __syncthreads();                     // atan table visible to every wave of the workgroup
+    double* atab = reinterpret_cast<double*>(lds_all + WPB * kTabOff);   // filled by the kernel wrapper, barrier included
     if (sidx >= n_streams) return;       // a last, partly filled workgroup
     OpvStream& st = streams[sidx];
 
@@ -306,6 +347,14 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                      : "memory");
     };
     const uint32_t lds_base = uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds);
+    [[maybe_unused]] const uint32_t xchg = uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(lds_all + WPB * kTabOff + 33 * kTabRow * 8));
+    [[maybe_unused]] uint32_t seq = 0, timeouts = 0;       // symbols of this launch so far; pos(seq) / fo(seq) carry that tag
+    [[maybe_unused]] auto publish = [&](uint32_t slot, double v, uint32_t tag) {   // value, then tag: every lane, same bytes
+        asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %0, %2 offset:8" : : "v"(xchg + slot + ((tag & 1u) << 4)), "v"(v), "v"(tag) : "memory");
+    };
+    [[maybe_unused]] auto await = [&](uint32_t slot, uint32_t tag, double& v) {
+        role_await(xchg + slot + ((tag & 1u) << 4), uni(tag), v, timeouts);
+    };
     auto issue_tile = [&](uint32_t t) {
         // tile t -> slot t&1: 8 wave instructions; an even tile's first 16 B are mirrored into the
         // guard behind the ring. The capture's last, incomplete 16 bytes (n_avail not a multiple
@@ -330,12 +379,19 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         }
     };
     // lowest sample any lane can touch at the first symbol of this launch
-    uint32_t t_lo = (origin >= kBack ? origin - kBack : 0u) / kTile;
-    issue_tile(t_lo);
-    issue_tile(t_lo + 1u);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): both tiles (and the guard) landed
+    constexpr uint32_t kBackR = kBack + (kDual ? 44u : 0u), kAheadR = kAhead + (kDual ? 44u : 0u);   // dual: the other wave may be a symbol behind
+    uint32_t t_lo = (origin >= kBackR ? origin - kBackR : 0u) / kTile;
+    if constexpr (kT) {
+        issue_tile(t_lo);
+        issue_tile(t_lo + 1u);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): both tiles (and the guard) landed
+    }
+    if constexpr (kDual) {
+        if constexpr (kF) publish(kXchgFo, st.freq_offset, 0u);   // T awaits fo(seq) at every symbol, the launch's first included
+        __syncthreads();                 // the first tiles before F's first tap
+    }
     bool evt_issue = true;               // next tile event: request tile t_lo+2 (else: wait for the newest)
-    uint32_t next_evt = (t_lo + 1u) * kTile + kBack;
+    uint32_t next_evt = (t_lo + 1u) * kTile + kBackR;
 
     for (;;) {
         // ---- which demodulate() call comes next (ref :1026 / :1088 / :1173) ----------------
@@ -372,14 +428,14 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 if (evt_issue) {
                     // the lowest tap has left tile t_lo for good: refill its slot with tile
                     // t_lo+2 (asynchronous; first needed a whole tile = ~51 symbols from now)
-                    issue_tile(t_lo + 2u);
+                    if constexpr (kT) issue_tile(t_lo + 2u);   // (F keeps the schedule only: same batches in both waves)
                     ++t_lo;
                     evt_issue = false;
-                    next_evt = (t_lo + 1u) * kTile - kAhead;
+                    next_evt = (t_lo + 1u) * kTile - kAheadR;
                 } else {
-                    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): requested a tile ago, no stall
+                    if constexpr (kT) __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): requested a tile ago, no stall
                     evt_issue = true;
-                    next_evt = (t_lo + 1u) * kTile + kBack;
+                    next_evt = (t_lo + 1u) * kTile + kBackR;
                 }
             }
             // j more symbols are safe iff gb + 42 j + 1 < next_evt and b + 1 + 42 j + 50 <= N
@@ -430,6 +486,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             const int d_r = (int)(short)(w1 & 0xFFFF) - s0r, d_i = (w1 >> 16) - s0i;
             const double lr = fma(f, (double)d_r, (double)s0r);              // ref :122-128
             const double li = fma(f, (double)d_i, (double)s0i);
+            if constexpr (ROLE == 1) await(kXchgFo, seq, fo);       // the frequency the AFC wave derived from symbol k-1
             double xs, xc;
             if constexpr (kWide) {
                 // -o takes any value (ref :1004-1005) and the AFC clamp (:303) first acts at the END of the
@@ -450,21 +507,21 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             // behind the VALU write of their source: the sigma-free halves of the early/late
             // products, the X[40] hand-over (lane 50) and the soft-ring cursor fill them.
             const double o1 = zr * aO, o2 = zi * bO, o3 = zi * aO, o4 = zr * bO;
-            const double eA = zr * aE;
+            [[maybe_unused]] double eA = 0, eB = 0, lA = 0, lB = 0;
+            if constexpr (kT) eA = zr * aE;
             __builtin_amdgcn_sched_barrier(0);
             const double r13 = swap32_add(o1, o3), r24 = swap32_add(o2, o4);
             __builtin_amdgcn_sched_barrier(0);
-            const double eB = zi * aE, lA = zr * aL;
+            if constexpr (kT) { eB = zi * aE; lA = zr * aL; }
             __builtin_amdgcn_sched_barrier(0);
             double q1 = swap16_add(r13, r24);                       // rows 0..3: P1o..P4o partials
             __builtin_amdgcn_sched_barrier(0);
-            double lB = zi * aL;
-            asm volatile("" : "+v"(lB));
-            cur.x40c = readlane_d(xc, 50);
+            if constexpr (kT) { lB = zi * aL; asm volatile("" : "+v"(lB)); }
+            if constexpr (kF) cur.x40c = readlane_d(xc, 50);
             __builtin_amdgcn_sched_barrier(0);
             q1 = dpp_add<0x128>(q1);
             __builtin_amdgcn_sched_barrier(0);
-            cur.x40s = readlane_d(xs, 50);
+            if constexpr (kF) cur.x40s = readlane_d(xs, 50);
             __builtin_amdgcn_sched_barrier(0);
             q1 = dpp_add<0x124>(q1);
             __builtin_amdgcn_sched_barrier(0);
@@ -474,8 +531,8 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             __builtin_amdgcn_sched_barrier(0);
             q1 = dpp_add<0x122>(q1);
             __builtin_amdgcn_sched_barrier(0);
-            double fo_sum_next = fo_sum + fo;                       // sum of the fo every symbol USED
-            asm volatile("" : "+v"(fo_sum_next));
+            [[maybe_unused]] double fo_sum_next = 0;
+            if constexpr (kF) { fo_sum_next = fo_sum + fo; asm volatile("" : "+v"(fo_sum_next)); }   // sum of the fo every symbol USED
             __builtin_amdgcn_sched_barrier(0);
             q1 = dpp_add<0x121>(q1);
             __builtin_amdgcn_sched_barrier(0);
@@ -507,21 +564,37 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             //   z = (S conj(S_prev)) * conj(X40_prev) * (+/- j)
             // With the previous S scaled by sg (prs = sg pr, pis = sg pi) the (+/- j) becomes a fixed
             // one: z = (cx, cy).
-            const double szi = sg * zi, szr = sg * zr;
-            const double wEr = fma(szi, bE, eA), wEi = fma(-szr, bE, eB);
-            const double wLr = fma(szi, bL, lA), wLi = fma(-szr, bL, lB);
-            double ted, pd = 0.0;
+            [[maybe_unused]] double wEr = 0, wEi = 0, wLr = 0, wLi = 0;
+            if constexpr (kT) {
+                const double szi = sg * zi, szr = sg * zr;
+                wEr = fma(szi, bE, eA); wEi = fma(-szr, bE, eB);
+                wLr = fma(szi, bL, lA); wLi = fma(-szr, bL, lB);
+            }
+            [[maybe_unused]] double ted = 0, pd = 0.0;
             [[maybe_unused]] double dr = 0, di = 0, cx = 0, cy = 0, ax = 0, ay = 0, mx = 1.0, mn = 0, ratio = 0, dm_ = 1.0;
             [[maybe_unused]] double2 c01{0, 0}, c23{0, 0}, c45{0, 0}, c67{0, 0};
             [[maybe_unused]] double c8 = 0, h = 0;
-            double q2;
-            if constexpr (kFirst) {
-                const double hre = swap32_add(wEr, wLr), him = swap32_add(wEi, wLi);   // lanes <32: E, >=32: L
-                q2 = swap16_add(hre, him);                          // rows: E.re, E.im, L.re, L.im partials
-                q2 = dpp_add<0x128>(q2);
-                q2 = dpp_add<0x124>(q2);
-                q2 = dpp_add<0x122>(q2);
-                q2 = dpp_add<0x121>(q2);
+            [[maybe_unused]] double q2 = 0;
+            if constexpr (kFirst || ROLE == 1) {
+                if constexpr (kT) {
+                    const double hre = swap32_add(wEr, wLr), him = swap32_add(wEi, wLi);   // lanes <32: E, >=32: L
+                    q2 = swap16_add(hre, him);                      // rows: E.re, E.im, L.re, L.im partials
+                    q2 = dpp_add<0x128>(q2);
+                    q2 = dpp_add<0x124>(q2);
+                    q2 = dpp_add<0x122>(q2);
+                    q2 = dpp_add<0x121>(q2);
+                }
+            } else if constexpr (ROLE == 2) {
+                // the AFC wave: the phase detector's operands as one chain (no early / late reduction to hide in)
+                dr = fma(sg, P2o, P1o);
+                di = fma(-sg, P4o, P3o);
+                const double prs = fma(sg, prv.a, prv.b), pis = fma(sg, prv.c, -prv.d);
+                const double ar = fma(dr, prs, di * pis), ai = fma(di, prs, -(dr * pis));
+                cy = fma(ar, prv.x40c, ai * prv.x40s);              // Im z
+                cx = fma(ar, prv.x40s, -(ai * prv.x40c));           // Re z
+                ax = fabs(cx); ay = fabs(cy);
+                asm("v_max_f64 %0, |%3|, |%4|\n\tv_min_f64 %1, |%3|, |%4|\n\tv_max_f64 %2, %0, %5"
+                    : "=&v"(mx), "=&v"(mn), "=&v"(dm_) : "v"(cx), "v"(cy), "v"(kc_tiny));
             } else {
                 dr = fma(sg, P2o, P1o);
                 asm volatile("" : "+v"(dr));
@@ -565,19 +638,37 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 asm("v_max_f64 %0, |%3|, |%4|\n\tv_min_f64 %1, |%3|, |%4|\n\tv_max_f64 %2, %0, %5"
                     : "=&v"(mx), "=&v"(mn), "=&v"(dm_) : "v"(cx), "v"(cy), "v"(kc_tiny));
             }
-            const double Eim = readlane_d(q2, 16), Lim = readlane_d(q2, 48);
-            const double Ere = readlane_d(q2, 0), Lre = readlane_d(q2, 32);
-            __builtin_amdgcn_sched_barrier(0);
-            const double ee = fma(Ere, Ere, Eim * Eim), el = fma(Lre, Lre, Lim * Lim);
-            const double num = el - ee, den = el + ee + kc_eps;     // ted = num/den (ref :275/:279)
+            [[maybe_unused]] double num = 0, den = 1.0;
+            if constexpr (kT) {
+                const double Eim = readlane_d(q2, 16), Lim = readlane_d(q2, 48);
+                const double Ere = readlane_d(q2, 0), Lre = readlane_d(q2, 32);
+                __builtin_amdgcn_sched_barrier(0);
+                const double ee = fma(Ere, Ere, Eim * Eim), el = fma(Lre, Lre, Lim * Lim);
+                num = el - ee; den = el + ee + kc_eps;              // ted = num/den (ref :275/:279)
+            }
 
             // ---- 3. divides, timing loop, AFC ---------------------------------------------------------
-            if constexpr (kFirst) {
-                double y = __builtin_amdgcn_rcp(den);
-                y = fma(fma(-den, y, 1.0), y, y);
-                y = fma(fma(-den, y, 1.0), y, y);
-                ted = num * y;
-                ted = fma(fma(-den, ted, num), y, ted);
+            if constexpr (kFirst || ROLE == 1) {
+                if constexpr (kT) {
+                    double y = __builtin_amdgcn_rcp(den);
+                    y = fma(fma(-den, y, 1.0), y, y);
+                    y = fma(fma(-den, y, 1.0), y, y);
+                    ted = num * y;
+                    ted = fma(fma(-den, ted, num), y, ted);
+                }
+            } else if constexpr (ROLE == 2) {
+                const double dm = dm_;                              // max(mx, 1e-100)
+                double y = __builtin_amdgcn_rcp(dm);
+                y = fma(fma(-dm, y, 1.0), y, y);
+                y = fma(fma(-dm, y, 1.0), y, y);
+                ratio = mn * y;
+                ratio = fma(fma(-dm, ratio, mn), y, ratio);
+                const double kd = rint(ratio * kc_32);
+                const int k = (int)kd;
+                h = fma(kd, kc_m1_32, ratio);
+                const unsigned char* rowb = reinterpret_cast<const unsigned char*>(atab) + __umul24((unsigned)k, kTabRow * 8u);
+                const double2* trow = reinterpret_cast<const double2*>(rowb);
+                c8 = reinterpret_cast<const double*>(rowb)[8]; c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
             } else {
                 // the two divides of the symbol on one reciprocal: ted and mn/mx for the phase
                 // detector; den in [1e-10, 2e12], dm in [1e-100, 1e12]
@@ -604,18 +695,21 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             __builtin_amdgcn_sched_barrier(0);
 
             // ---- timing loop, soft log, next symbol's taps ------------------------------------------
+            if constexpr (kT) {
             tf = clampd(fma(kc_beta, ted, tf), kc_ntfmax, kc_tfmax);  // beta (ref :118,:283-284)
             // alpha (ref :117,:285). The reference then clamps to +/-2 (:286): |ted| < 1 (num = L - E, den = L + E + 1e-10,
             // L, E >= 0) and |tf| <= 0.1, so |adj| <= 0.105 and that clamp can never act - it is not issued.
             const double adj = fma(kc_alpha, ted, tf);
             pos += 40.0 + adj;                                      // ref :313
+            if constexpr (kDual) publish(kXchgPos, pos, seq + 1u);  // the AFC wave is waiting for it
             fetch_addr(pos, false);                                 // pos >= 38 after any symbol
             __builtin_amdgcn_sched_barrier(0);
             fetch_read();                                           // next symbol's taps requested as soon as their address exists
             __builtin_amdgcn_sched_barrier(0);
-            *(gdouble*)(soft_base + my_soft_off) = soft;            // all lanes, same value and address
+            }
+            if constexpr (kF) *(gdouble*)(soft_base + my_soft_off) = soft;   // all lanes, same value and address
             [[maybe_unused]] double pd_off = 0;
-            if constexpr (!kFirst) {
+            if constexpr (!kFirst && kF) {
                 // cx < 0: pi - pd, as a +/-1 multiplier and a 0/pi offset built from the sign bit
                 sx = mkd((dhi(cx) & (int)0x80000000) | 0x3ff00000, dlo(sx));
                 pd_off = fma(-sx, kc_halfpi, kc_halfpi);
@@ -625,7 +719,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             }
 
             // ---- AFC ------------------------------------------------------------------------------
-            if constexpr (!kFirst) {
+            if constexpr (!kFirst && kF) {
                 pd = fma(c8, h, c67.y);                             // degree-8 Horner
                 pd = fma(pd, h, c67.x);
                 pd = fma(pd, h, c45.y);
@@ -645,15 +739,23 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                     edge_ties += uni((uint32_t)sp.y);
                 }
             }
-            if constexpr (!kFirst) {                                // ref :300-303
+            if constexpr (!kFirst && kF) {                          // ref :300-303
                 // (written as instructions: through fmin/fmax hipcc re-canonicalises the two loop-invariant
                 // bounds with a v_max_f64 x, x each, every symbol)
                 const double fo_new = fma(kc_gain, pd, fo);
                 asm("v_max_f64 %0, %1, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(fo) : "v"(fo_new), "v"(kc_nfomax), "v"(kc_fomax));
             }
-            fo_sum = fo_sum_next;                                   // (the silence rule above needs the sum BEFORE this symbol)
-            // prev <- this symbol's on-time correlations (ref :309-310)
-            cur.a = P1o; cur.b = P2o; cur.c = P3o; cur.d = P4o;
+            if constexpr (ROLE == 2) publish(kXchgFo, fo, seq + 1u);    // the timing wave needs it for the next symbol's LO
+            if constexpr (kF) {
+                fo_sum = fo_sum_next;                               // (the silence rule above needs the sum BEFORE this symbol)
+                // prev <- this symbol's on-time correlations (ref :309-310)
+                cur.a = P1o; cur.b = P2o; cur.c = P3o; cur.d = P4o;
+            }
+            if constexpr (kDual) ++seq;
+            if constexpr (ROLE == 2) {
+                await(kXchgPos, seq, pos);                          // the position this symbol led to (also the end-of-call test's)
+                fetch(pos, false);                                  // next symbol's taps (speculative at the end of a call)
+            }
         };
 
         if (uni_lt(pos + 40.0 + 10.0, Nd)) {               // ref :221
@@ -662,7 +764,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             symbol(TagFirst{}, qp, qp);
             if (__builtin_expect(uni_lt(2000.0, fabs(fo)), 0) && uni_lt(pos + 40.0 + 10.0, Nd)) {
                 (void)housekeeping(pos);                   // an out-of-range -o is still in force for one more symbol
-                fetch(pos, false);
+                if constexpr (!kDual) fetch(pos, false);
                 symbol(TagSecond{}, qq, qp);
                 qp = qq;
             }
@@ -672,8 +774,9 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             // bookkeeping. Symbols go in pairs so that the "previous correlation" registers
             // alternate instead of being copied.
             while (uni_lt(pos + 40.0 + 10.0, Nd)) {        // ref :221
+                if constexpr (kDual) { if (__builtin_expect(timeouts != 0u, 0)) break; }   // the partner wave never came
                 uint32_t pairs = uni(housekeeping(pos)) >> 1;
-                fetch(pos, false);
+                if constexpr (!kDual) fetch(pos, false);   // (dual: the margins of the tile events make the early fetch final)
                 for (; pairs != 0u; --pairs) {
                     symbol(TagSteady{}, qq, qp);
                     symbol(TagSteady{}, qp, qq);
@@ -684,13 +787,15 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         }
 
         // ---- end of this demodulate() call (ref :318-328, :1067-1076) ------------------------
+        if constexpr (kDual) { if (timeouts != 0u) { overflow = 2; break; } }   // give up loudly instead of hanging
         const uint32_t nsym_call = ((soft_off - soft_off0) & soft_bmask) >> 3;
         const uint32_t used = uni((uint32_t)pos);
         mu = pos - (double)used;
         const uint32_t leftover = N - used;
-        if (lane == 0) {                                   // chunk log is a ring
+        if (lane == 0) {                                   // chunk log is a ring (dual: each wave writes what it owns)
             double* c = st.chunk_log + 5 * (size_t)(n_chunks % st.cap_chunks);
-            c[0] = fo; c[1] = tf; c[2] = mu; c[3] = (double)leftover; c[4] = (double)nsym_call;
+            if constexpr (kF) c[0] = fo;
+            if constexpr (kT) { c[1] = tf; c[2] = mu; c[3] = (double)leftover; c[4] = (double)nsym_call; }
         }
         ++n_chunks;
         n_soft += nsym_call;
@@ -700,12 +805,17 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     }
 
     if (lane == 0) {
-        st.freq_offset = fo; st.timing_freq = tf; st.mu = mu;
-        st.p1r = qp.a; st.p1i = qp.b; st.p2r = qp.c; st.p2i = qp.d; st.x40c = qp.x40c; st.x40s = qp.x40s;
-        st.fo_sum = fo_sum;
+        if constexpr (kF) {
+            st.freq_offset = fo;
+            st.p1r = qp.a; st.p1i = qp.b; st.p2r = qp.c; st.p2i = qp.d; st.x40c = qp.x40c; st.x40s = qp.x40s;
+            st.fo_sum = fo_sum;
+            st.edge_ties = edge_ties;
+        }
+        if constexpr (kT) {
+        st.timing_freq = tf; st.mu = mu;
         st.origin = origin; st.n_soft = n_soft; st.total_samples = total_samples;
         st.n_chunks = n_chunks; st.tail_done = tail_done; st.overflow = overflow;
-        st.stalled = stalled; st.edge_ties = edge_ties;
+        st.stalled = stalled;
         // where and at which clock this stream's wave ran (two scalar reads per launch; opv_tap_wave_info)
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -713,15 +823,39 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         st.dbg_hw_id = hw; st.dbg_xcc_id = xcc;
         st.dbg_cycles = __builtin_amdgcn_s_memtime() - dbg_t0;
         st.dbg_ticks = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+        }
     }
+}
+
+// atan table into LDS (shared by the workgroup's waves); the caller's barrier makes it visible
+template <int NT>
+__device__ __forceinline__ void load_atan_table(unsigned char* lds_tab) {
+    double* atab = reinterpret_cast<double*>(lds_tab);
+    for (int i = threadIdx.x; i < 33 * (int)kTabRow; i += NT) atab[i] = (&kOpvAtanTab[0][0])[i];
 }
 
 extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
                                                                  int n_streams) {
-    msk_frontend_body<1>(streams, cfg, n_streams);
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[kTabOff + 33 * kTabRow * 8];
+    load_atan_table<64>(lds_all + kTabOff);
+    __syncthreads();
+    msk_frontend_body<1, 0>(streams, cfg, n_streams, lds_all);
 }
 // four streams per workgroup: one per SIMD of a CU by construction (see msk_frontend_body)
 extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_wg4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
                                                                       int n_streams) {
-    msk_frontend_body<4>(streams, cfg, n_streams);
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * kTabOff + 33 * kTabRow * 8];
+    load_atan_table<256>(lds_all + 4 * kTabOff);
+    __syncthreads();
+    msk_frontend_body<4, 0>(streams, cfg, n_streams, lds_all);
+}
+// two waves per stream: wave 0 = timing loop (ROLE 1), wave 1 = AFC (ROLE 2), on two SIMDs of one CU
+extern "C" __global__ __launch_bounds__(128) void k_msk_frontend_dual(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
+                                                                       int n_streams) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[kTabOff + 33 * kTabRow * 8 + kXchgBytes];
+    load_atan_table<128>(lds_all + kTabOff);
+    if (threadIdx.x < kXchgBytes / 4) reinterpret_cast<uint32_t*>(lds_all + kTabOff + 33 * kTabRow * 8)[threadIdx.x] = 0xFFFFFFFFu;   // no tag yet
+    __syncthreads();
+    if (threadIdx.x < 64) msk_frontend_body<1, 1>(streams, cfg, n_streams, lds_all);
+    else msk_frontend_body<1, 2>(streams, cfg, n_streams, lds_all);
 }

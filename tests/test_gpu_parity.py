@@ -160,7 +160,7 @@ def test_afc_alpha_flag(amd, oracle, iq10):
 
 def test_two_waves_per_stream_mapping_is_exact(amd, oracle, iq10, iq100):
     """opv_set_frontend(-2): the timing loop and the AFC on two wavefronts that exchange pos / fo through LDS every
-    symbol (csrc/k_frontend_dual.hip; not selected automatically). Same bar as the other mappings: clean, offset + noise,
+    symbol (k_msk_frontend_dual = ROLE 1 / 2 of csrc/k_frontend.hip's body; not selected automatically). Same bar as the other mappings: clean, offset + noise,
     an out-of-range -o, ragged lengths, -s and batch, several streams in one context."""
     caps = [iq10, impair(iq10, amp=3000.0, f0_hz=-1700.0, ebn0_db=9.0, seed=3), impair(iq100[: 2 * 40 * 86720], amp=2000.0, f0_hz=900.0, ebn0_db=14.0, seed=8),
             iq10[: 2 * 123457], iq10[: 2 * 86719], np.zeros(2 * 90000, np.int16)]
