@@ -263,9 +263,10 @@ __device__ inline void role_await(uint32_t a, uint32_t want, double& v, uint32_t
 // ROLE 0 (1111 vs 1043 cycles per symbol at 64 streams): each wave's LDS round trips and cross-lane hazard slots are no
 // longer filled by the other loop's arithmetic, and the partner is waited for once per symbol. It is
 // never selected automatically (opv_set_frontend(ctx, -2)).
-template <int WPB, int ROLE>
+template <int WPB, int ROLE, bool RMAC = false>
 __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ streams, OpvGlobalCfg cfg, int n_streams,
                                                   unsigned char* lds_all) {
+    static_assert(!RMAC || ROLE == 0, "the row-broadcast reduction is a variant of the one-wave mapping");
     constexpr bool kT = ROLE != 2;       // this wave runs the timing loop (and stages the tiles)
     constexpr bool kF = ROLE != 1;       // this wave runs the AFC (and logs the soft symbols)
     constexpr bool kDual = ROLE != 0;
@@ -281,15 +282,43 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     OpvStream& st = streams[sidx];
 
     // ---- per-lane constants -------------------------------------------------------------
-    const double kf = (double)(lane - 10);
+    // RMAC: rows of 15 samples (lane 16 r + n <-> sample 15 r + n, n < 15; a row's last lane repeats its neighbour's
+    // sample and carries no weight), so that the 60 samples take 15 broadcast steps per row instead of 16
+    const int jsamp = RMAC ? lane - (lane >> 4) - ((lane & 15) == 15 ? 1 : 0) : lane;
+    const double kf = (double)(jsamp - 10);
     const double kfs = kf * kDeltaPerHz;
     // T_1[i] = exp(-j 2 pi i / 160) = (cos(pi i/80), -sin(pi i/80)); zero outside a gate's window
     double aE = 0, bE = 0, aO = 0, bO = 0, aL = 0, bL = 0;
-    {
+    if constexpr (!RMAC) {
         double sn, cs;
         if (lane < 40) { sincospi((double)lane / 80.0, &sn, &cs); aE = cs; bE = -sn; }
         if (lane >= 10 && lane < 50) { sincospi((double)(lane - 10) / 80.0, &sn, &cs); aO = cs; bO = -sn; }
         if (lane >= 20 && lane < 60) { sincospi((double)(lane - 20) / 80.0, &sn, &cs); aL = cs; bL = -sn; }
+    }
+    // RMAC: output t = lane & 15 of every row is one of the symbol's twelve window sums, and wr[n] / wi[n] are the
+    // weights of Re / Im Z of the row's n-th sample in it (see `symbol_r`):
+    //   t = 0..3   on-time P1 = sum Zr a, P2 = sum Zi b, P3 = sum Zi a, P4 = sum Zr b        (window j in [10, 50), i = j - 10)
+    //   t = 4, 5   Re of the early correlation of tone 1 / tone 2, t = 12, 13 its Im          (j in [0, 40),  i = j)
+    //   t = 6, 7   Re of the late correlation of tone 1 / tone 2,  t = 14, 15 its Im          (j in [20, 60), i = j - 20)
+    //   C_1 = sum Z conj(T_1[i]) = (sum Zr a + Zi b, sum Zi a - Zr b), C_2 = sum Z T_1[i] = (sum Zr a - Zi b, sum Zi a + Zr b)
+    [[maybe_unused]] double wr[15], wi[15];
+    if constexpr (RMAC) {
+        const int row = lane >> 4, t = lane & 15;
+        const int gate = t < 4 ? 1 : ((t & 2) ? 2 : 0);          // 0 early, 1 on-time, 2 late
+#pragma unroll
+        for (int n = 0; n < 15; ++n) {
+            const int i = 15 * row + n - 10 * gate;
+            double sn, cs;
+            sincospi((double)i / 80.0, &sn, &cs);
+            const bool in = i >= 0 && i < 40 && !(t >= 8 && t < 12);
+            const double a = in ? cs : 0.0, b = in ? -sn : 0.0;
+            double r_, i_;
+            if (t < 4) { r_ = (t == 0) ? a : (t == 3 ? b : 0.0); i_ = (t == 1) ? b : (t == 2 ? a : 0.0); }
+            else if (t < 8) { r_ = a; i_ = (t & 1) ? -b : b; }    // Re C_1 / C_2
+            else { r_ = (t & 1) ? b : -b; i_ = a; }               // Im C_1 / C_2
+            wr[n] = r_; wi[n] = i_;
+            asm volatile("" : "+v"(wr[n]), "+v"(wi[n]));
+        }
     }
     SinCosK sck;
     sck.s0 = -0x1.5555555555555p-3; sck.s1 = 0x1.1111111110f73p-7; sck.s2 = -0x1.a01a019da51d6p-13;
@@ -758,14 +787,187 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             }
         };
 
+        // The same symbol with the ROW-BROADCAST reduction (RMAC; ROLE 0 only). gfx950's DP-ALU DPP form
+        //   v_fmac_f64_dpp acc, src0 row_newbcast:n, src1      acc[l] += src0[row(l), lane n] * src1[l]
+        // lets the 16 lanes of a row form 16 differently weighted sums of the row's samples, one broadcast step per
+        // sample and component: 2 x 15 full-rate FMACs produce ALL twelve window sums of the symbol (on-time P1..P4, early
+        // and late correlations of BOTH tones) as row partials in lanes t = lane & 15, with no product instructions, no
+        // dominant-tone dependence and no v_readlane. One all-reduce over the four rows (two permlane swaps of the value
+        // with itself) completes them; v_mov_b64_dpp row_newbcast hands the numbers the loop filters need to every lane
+        // (one instruction per double instead of two v_readlane + the SGPR-operand restrictions), and the four early /
+        // late energies are formed lane-parallel (square, row_ror:8, add: Re at t, Im at t + 8) before they are handed out.
+        // 22 VALU instructions and all s_nop fewer per symbol than `symbol` (scripts/microbench/dpp64.hip has the
+        // instruction costs). Sections 3 onward are the ROLE 0 statements of `symbol`.
+        [[maybe_unused]] auto symbol_r = [&](auto tag, PrevSums& cur, const PrevSums& prv) {
+            constexpr bool kFirst = decltype(tag)::first;
+            constexpr bool kWide = decltype(tag)::wide;
+            const int s0r = (int)(short)(w0 & 0xFFFF), s0i = w0 >> 16;      // ref :1023
+            const int d_r = (int)(short)(w1 & 0xFFFF) - s0r, d_i = (w1 >> 16) - s0i;
+            const double lr = fma(f, (double)d_r, (double)s0r);              // ref :122-128
+            const double li = fma(f, (double)d_i, (double)s0i);
+            double xs, xc;
+            if constexpr (kWide) {
+                if (__builtin_expect(uni_lt(2000.0, fabs(fo)), 0)) sincos(kfs * fo, &xs, &xc);
+                else expj_small(kfs, fo, sck, xs, xc);
+            } else {
+                expj_small(kfs, fo, sck, xs, xc);
+            }
+            const double zr = fma(lr, xc, li * xs);                         // Z = Lam * conj(X)
+            const double zi = fma(li, xc, -(lr * xs));
+            __builtin_amdgcn_sched_barrier(0);
+
+            // ---- 1. the twelve window sums: row partials by broadcast-FMAC (the two moves are the wait states a DPP
+            // read needs behind the VALU write of Z), two accumulators
+            double acc0, acc1;
+#define OPV_RB(N) "v_fmac_f64_dpp %0, %2, %[r" #N "] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t" \
+                  "v_fmac_f64_dpp %1, %3, %[i" #N "] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+            asm("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\t" OPV_RB(0) OPV_RB(1) OPV_RB(2) OPV_RB(3) OPV_RB(4) OPV_RB(5) OPV_RB(6) OPV_RB(7)
+                : "=&v"(acc0), "=&v"(acc1)
+                : "v"(zr), "v"(zi), [r0] "v"(wr[0]), [i0] "v"(wi[0]), [r1] "v"(wr[1]), [i1] "v"(wi[1]), [r2] "v"(wr[2]), [i2] "v"(wi[2]),
+                  [r3] "v"(wr[3]), [i3] "v"(wi[3]), [r4] "v"(wr[4]), [i4] "v"(wi[4]), [r5] "v"(wr[5]), [i5] "v"(wi[5]),
+                  [r6] "v"(wr[6]), [i6] "v"(wi[6]), [r7] "v"(wr[7]), [i7] "v"(wi[7]));
+            asm(OPV_RB(8) OPV_RB(9) OPV_RB(10) OPV_RB(11) OPV_RB(12) OPV_RB(13) OPV_RB(14)
+                : "+v"(acc0), "+v"(acc1)
+                : "v"(zr), "v"(zi), [r8] "v"(wr[8]), [i8] "v"(wi[8]), [r9] "v"(wr[9]), [i9] "v"(wi[9]), [r10] "v"(wr[10]), [i10] "v"(wi[10]),
+                  [r11] "v"(wr[11]), [i11] "v"(wi[11]), [r12] "v"(wr[12]), [i12] "v"(wi[12]), [r13] "v"(wr[13]), [i13] "v"(wi[13]),
+                  [r14] "v"(wr[14]), [i14] "v"(wi[14]));
+#undef OPV_RB
+            __builtin_amdgcn_sched_barrier(0);
+            cur.x40c = readlane_d(xc, 53);                          // sample 50 = X[40] sits in row 3, lane 5
+            cur.x40s = readlane_d(xs, 53);
+            double v = acc0 + acc1;
+            v = swap32_add(v, v);                                   // all-reduce over the four rows
+            v = swap16_add(v, v);
+            __builtin_amdgcn_sched_barrier(0);
+            const double sq = v * v;
+            const uint32_t my_soft_off = soft_off;
+            soft_off = (soft_off + 8u) & soft_bmask;
+            asm volatile("" : "+v"(soft_off));
+            double fo_sum_next = fo_sum + fo;                       // sum of the fo every symbol USED
+            asm volatile("" : "+v"(fo_sum_next));
+            __builtin_amdgcn_sched_barrier(0);
+            double P1o, P2o, P3o, P4o;
+            asm("v_mov_b64_dpp %0, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b64_dpp %1, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b64_dpp %2, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b64_dpp %3, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+                : "=&v"(P1o), "=&v"(P2o), "=&v"(P3o), "=&v"(P4o) : "v"(v));
+            __builtin_amdgcn_sched_barrier(0);
+            // energies of the early / late correlations, lane-parallel: t = 4..7 -> |E_1|^2, |E_2|^2, |L_1|^2, |L_2|^2
+            const double sh = mkd(__builtin_amdgcn_mov_dpp(dhi(sq), 0x128, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(dlo(sq), 0x128, 0xF, 0xF, true));
+            const double en = sq + sh;
+            __builtin_amdgcn_sched_barrier(0);
+            const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;        // S_1 (tone -13550)
+            const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;        // S_2 (tone +13550)
+            const double en1 = fma(s1r_, s1r_, s1i_ * s1i_);        // ref :264-265
+            const double en2 = fma(s2r_, s2r_, s2i_ * s2i_);
+            const double soft = en2 - en1;                          // ref :268
+            nsg = mkd((dhi(soft) & (int)0x80000000) | 0x3ff00000, dlo(nsg));
+            const double sg = -nsg;
+            __builtin_amdgcn_sched_barrier(0);
+            double EE1, EE2, LL1, LL2;
+            asm("v_mov_b64_dpp %0, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b64_dpp %1, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b64_dpp %2, %4 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                "v_mov_b64_dpp %3, %4 row_newbcast:7 row_mask:0xf bank_mask:0xf"
+                : "=&v"(EE1), "=&v"(EE2), "=&v"(LL1), "=&v"(LL2) : "v"(en));
+            const bool dom1 = soft < 0.0;                           // ref :272 / :291 (a tie gives +0: tone 2)
+            const double ee = dom1 ? EE1 : EE2, el = dom1 ? LL1 : LL2;
+            const double num = el - ee, den = el + ee + kc_eps;     // ted = num/den (ref :275/:279)
+
+            double ted = 0, pd = 0.0;
+            double dr = 0, di = 0, cx = 0, cy = 0, ax = 0, ay = 0, mx = 1.0, mn = 0, ratio = 0, dm_ = 1.0;
+            double2 c01{0, 0}, c23{0, 0}, c45{0, 0}, c67{0, 0};
+            double c8 = 0, h = 0;
+            if constexpr (!kFirst) {
+                // phase detector operands: dom * conj(prev) (ref :299), see `symbol`
+                dr = fma(sg, P2o, P1o);
+                di = fma(-sg, P4o, P3o);
+                const double prs = fma(sg, prv.a, prv.b), pis = fma(sg, prv.c, -prv.d);
+                const double ar = fma(dr, prs, di * pis), ai = fma(di, prs, -(dr * pis));
+                cy = fma(ar, prv.x40c, ai * prv.x40s);              // Im z
+                cx = fma(ar, prv.x40s, -(ai * prv.x40c));           // Re z
+                ax = fabs(cx); ay = fabs(cy);
+                asm("v_max_f64 %0, |%3|, |%4|\n\tv_min_f64 %1, |%3|, |%4|\n\tv_max_f64 %2, %0, %5"
+                    : "=&v"(mx), "=&v"(mn), "=&v"(dm_) : "v"(cx), "v"(cy), "v"(kc_tiny));
+            }
+
+            // ---- 3. divides, timing loop, AFC: as in `symbol` -----------------------------------------
+            if constexpr (kFirst) {
+                double y = __builtin_amdgcn_rcp(den);
+                y = fma(fma(-den, y, 1.0), y, y);
+                y = fma(fma(-den, y, 1.0), y, y);
+                ted = num * y;
+                ted = fma(fma(-den, ted, num), y, ted);
+            } else {
+                const double dm = dm_;
+                const double tt = den * dm;
+                double y = __builtin_amdgcn_rcp(tt);
+                y = fma(fma(-tt, y, 1.0), y, y);
+                y = fma(fma(-tt, y, 1.0), y, y);
+                const double iden = y * dm, idm = y * den;
+                ratio = mn * idm;
+                ratio = fma(fma(-dm, ratio, mn), idm, ratio);
+                const double kd = rint(ratio * kc_32);
+                const int k = (int)kd;
+                h = fma(kd, kc_m1_32, ratio);
+                const unsigned char* rowb = reinterpret_cast<const unsigned char*>(atab) + __umul24((unsigned)k, kTabRow * 8u);
+                const double2* trow = reinterpret_cast<const double2*>(rowb);
+                c8 = reinterpret_cast<const double*>(rowb)[8]; c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
+                ted = num * iden;
+                ted = fma(fma(-den, ted, num), iden, ted);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            tf = clampd(fma(kc_beta, ted, tf), kc_ntfmax, kc_tfmax);  // beta (ref :118,:283-284)
+            const double adj = fma(kc_alpha, ted, tf);                // alpha (ref :117,:285); the +/-2 clamp (:286) cannot act
+            pos += 40.0 + adj;                                        // ref :313
+            fetch_addr(pos, false);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_read();
+            __builtin_amdgcn_sched_barrier(0);
+            *(gdouble*)(soft_base + my_soft_off) = soft;
+            if constexpr (!kFirst) {
+                sx = mkd((dhi(cx) & (int)0x80000000) | 0x3ff00000, dlo(sx));
+                const double pd_off = fma(-sx, kc_halfpi, kc_halfpi);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC17F);                 // lgkmcnt(1): the table row landed
+                __builtin_amdgcn_sched_barrier(0);
+                pd = fma(c8, h, c67.y);                             // degree-8 Horner
+                pd = fma(pd, h, c67.x);
+                pd = fma(pd, h, c45.y);
+                pd = fma(pd, h, c45.x);
+                pd = fma(pd, h, c23.y);
+                pd = fma(pd, h, c23.x);
+                pd = fma(pd, h, c01.y);
+                pd = fma(pd, h, c01.x);
+                pd = (ay > ax) ? kc_halfpi - pd : pd;               // octant fix-up
+                pd = fma(sx, pd, pd_off);
+                pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));  // sign of cy
+                if (__builtin_expect(uni_eq(mx, 0.0), 0)) {         // digital silence on either side
+                    const double2 sp = silence_pd(dr, di, prv, soft < 0.0, fo_sum, n_soft + (((my_soft_off - soft_off0) & soft_bmask) >> 3),
+                                                  P1o, P2o, P3o, P4o);
+                    pd = sp.x;
+                    edge_ties += uni((uint32_t)sp.y);
+                }
+                const double fo_new = fma(kc_gain, pd, fo);         // ref :300-303
+                asm("v_max_f64 %0, %1, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(fo) : "v"(fo_new), "v"(kc_nfomax), "v"(kc_fomax));
+            }
+            fo_sum = fo_sum_next;
+            cur.a = P1o; cur.b = P2o; cur.c = P3o; cur.d = P4o;     // prev <- this symbol's on-time correlations (ref :309-310)
+        };
+        auto sym = [&](auto tag, PrevSums& cur, const PrevSums& prv) {
+            if constexpr (RMAC) symbol_r(tag, cur, prv);
+            else symbol(tag, cur, prv);
+        };
+
         if (uni_lt(pos + 40.0 + 10.0, Nd)) {               // ref :221
             (void)housekeeping(pos);
             fetch(pos, true);
-            symbol(TagFirst{}, qp, qp);
+            sym(TagFirst{}, qp, qp);
             if (__builtin_expect(uni_lt(2000.0, fabs(fo)), 0) && uni_lt(pos + 40.0 + 10.0, Nd)) {
                 (void)housekeeping(pos);                   // an out-of-range -o is still in force for one more symbol
                 if constexpr (!kDual) fetch(pos, false);
-                symbol(TagSecond{}, qq, qp);
+                sym(TagSecond{}, qq, qp);
                 qp = qq;
             }
             // Batches: the end-of-call test and the tile events once, then as many symbols as are
@@ -778,10 +980,10 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 uint32_t pairs = uni(housekeeping(pos)) >> 1;
                 if constexpr (!kDual) fetch(pos, false);   // (dual: the margins of the tile events make the early fetch final)
                 for (; pairs != 0u; --pairs) {
-                    symbol(TagSteady{}, qq, qp);
-                    symbol(TagSteady{}, qp, qq);
+                    sym(TagSteady{}, qq, qp);
+                    sym(TagSteady{}, qp, qq);
                 }
-                symbol(TagSteady{}, qq, qp);
+                sym(TagSteady{}, qq, qp);
                 qp = qq;
             }
         }
@@ -848,6 +1050,21 @@ extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_wg4(OpvStream* 
     load_atan_table<256>(lds_all + 4 * kTabOff);
     __syncthreads();
     msk_frontend_body<4, 0>(streams, cfg, n_streams, lds_all);
+}
+// the same two launch shapes with the row-broadcast reduction (msk_frontend_body<.., 0, true>, `symbol_r`)
+extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_rb(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
+                                                                    int n_streams) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[kTabOff + 33 * kTabRow * 8];
+    load_atan_table<64>(lds_all + kTabOff);
+    __syncthreads();
+    msk_frontend_body<1, 0, true>(streams, cfg, n_streams, lds_all);
+}
+extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_rb_wg4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
+                                                                         int n_streams) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * kTabOff + 33 * kTabRow * 8];
+    load_atan_table<256>(lds_all + 4 * kTabOff);
+    __syncthreads();
+    msk_frontend_body<4, 0, true>(streams, cfg, n_streams, lds_all);
 }
 // two waves per stream: wave 0 = timing loop (ROLE 1), wave 1 = AFC (ROLE 2), on two SIMDs of one CU
 extern "C" __global__ __launch_bounds__(128) void k_msk_frontend_dual(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,

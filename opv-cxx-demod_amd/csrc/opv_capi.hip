@@ -21,6 +21,8 @@ extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg, const doubl
 extern "C" __global__ void k_msk_frontend(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_dual(OpvStream*, OpvGlobalCfg, int);
+extern "C" __global__ void k_msk_frontend_rb(OpvStream*, OpvGlobalCfg, int);
+extern "C" __global__ void k_msk_frontend_rb_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_coherent_frontend(OpvStream*, double, double);
@@ -460,6 +462,9 @@ extern "C" int opv_process(opv_ctx* c) {
         k_coherent_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, 2.0 * zeta * wn / fsym, wn * wn / (fsym * fsym));
     } else if (c->frontend == -2) {                        // two waves per stream (opv_set_frontend(-2))
         k_msk_frontend_dual<<<S, 128, 0, c->stream>>>(c->d_streams, g, S);
+    } else if (c->frontend == -3) {                        // one wave per stream, row-broadcast reduction (opv_set_frontend(-3))
+        if (S > kFrontendWg4MinStreams) k_msk_frontend_rb_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);
+        else k_msk_frontend_rb<<<S, 64, 0, c->stream>>>(c->d_streams, g, S);
     } else if (x4 && S <= kFrontendX4Wg4MaxStreams)        // up to two waves per SIMD: four waves (16 streams) per workgroup
         k_msk_frontend_x4_wg4<<<(S + 15) / 16, 256, 0, c->stream>>>(c->d_streams, g, S);
     else if (x4) k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
@@ -482,7 +487,7 @@ extern "C" int opv_process(opv_ctx* c) {
 
 extern "C" int opv_set_frontend(opv_ctx* c, int streams_per_wave) {
     if (!c) return fail(OPV_EINVAL, "null context");
-    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4 && streams_per_wave != -2)
+    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4 && streams_per_wave != -2 && streams_per_wave != -3)
         return fail(OPV_EINVAL, "opv_set_frontend: 0 (automatic), 1 or 4 streams per wave, -2 = two waves per stream");
     c->frontend = streams_per_wave;
     return OPV_OK;
