@@ -271,7 +271,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     constexpr bool kF = ROLE != 1;       // this wave runs the AFC (and logs the soft symbols)
     constexpr bool kDual = ROLE != 0;
     const int lane = threadIdx.x & 63;
-    const int wave = kDual ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = (kDual || WPB == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (a constant 0 lets the ring base fold into the tap address)
     const int sidx = kDual ? (int)blockIdx.x : (int)blockIdx.x * WPB + wave;
     const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 
@@ -298,13 +298,13 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     // RMAC: output t = lane & 15 of every row is one of the symbol's twelve window sums, and wr[n] / wi[n] are the
     // weights of Re / Im Z of the row's n-th sample in it (see `symbol_r`):
     //   t = 0..3   on-time P1 = sum Zr a, P2 = sum Zi b, P3 = sum Zi a, P4 = sum Zr b        (window j in [10, 50), i = j - 10)
-    //   t = 4, 5   Re of the early correlation of tone 1 / tone 2, t = 12, 13 its Im          (j in [0, 40),  i = j)
-    //   t = 6, 7   Re of the late correlation of tone 1 / tone 2,  t = 14, 15 its Im          (j in [20, 60), i = j - 20)
+    //   t = 4..7   Re of the early / late correlation of tone 1, then of tone 2 (E_1, L_1, E_2, L_2); t = 12..15 their Im
+    //              (early: j in [0, 40), i = j; late: j in [20, 60), i = j - 20)
     //   C_1 = sum Z conj(T_1[i]) = (sum Zr a + Zi b, sum Zi a - Zr b), C_2 = sum Z T_1[i] = (sum Zr a - Zi b, sum Zi a + Zr b)
     [[maybe_unused]] double wr[15], wi[15];
     if constexpr (RMAC) {
         const int row = lane >> 4, t = lane & 15;
-        const int gate = t < 4 ? 1 : ((t & 2) ? 2 : 0);          // 0 early, 1 on-time, 2 late
+        const int gate = t < 4 ? 1 : ((t & 1) ? 2 : 0);          // 0 early, 1 on-time, 2 late
 #pragma unroll
         for (int n = 0; n < 15; ++n) {
             const int i = 15 * row + n - 10 * gate;
@@ -314,8 +314,8 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             const double a = in ? cs : 0.0, b = in ? -sn : 0.0;
             double r_, i_;
             if (t < 4) { r_ = (t == 0) ? a : (t == 3 ? b : 0.0); i_ = (t == 1) ? b : (t == 2 ? a : 0.0); }
-            else if (t < 8) { r_ = a; i_ = (t & 1) ? -b : b; }    // Re C_1 / C_2
-            else { r_ = (t & 1) ? b : -b; i_ = a; }               // Im C_1 / C_2
+            else if (t < 8) { r_ = a; i_ = (t & 2) ? -b : b; }    // Re C_1 / C_2
+            else { r_ = (t & 2) ? b : -b; i_ = a; }               // Im C_1 / C_2
             wr[n] = r_; wi[n] = i_;
             asm volatile("" : "+v"(wr[n]), "+v"(wi[n]));
         }
@@ -330,7 +330,10 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     double kc_tfmax = 0.1, kc_beta = 0.00001, kc_alpha = 0.005, kc_fomax = 2000.0, kc_eps = 1e-10;
     double kc_tiny = 1e-100;
     asm volatile("" : "+v"(kc_tiny));
+    if constexpr (RMAC) kc_tiny = __builtin_canonicalize(kc_tiny);   // (symbol_r uses it through fmax)
     double kc_halfpi = 1.57079632679489661923, kc_32 = 32.0, kc_m1_32 = -1.0 / 32.0, kc_gain = st.afc_alpha * (kSymRate / kTwoPi);
+    [[maybe_unused]] double kc_64 = 64.0, kc_m1_64 = -1.0 / 64.0;
+    asm volatile("" : "+v"(kc_64), "+v"(kc_m1_64));
     asm volatile("" : "+v"(kc_tfmax), "+v"(kc_beta), "+v"(kc_alpha), "+v"(kc_fomax), "+v"(kc_eps));
     asm volatile("" : "+v"(kc_halfpi), "+v"(kc_32), "+v"(kc_m1_32), "+v"(kc_gain));
     const double kc_nfomax = __builtin_canonicalize(-kc_fomax), kc_ntfmax = __builtin_canonicalize(-kc_tfmax);
@@ -793,11 +796,15 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         // sample and component: 2 x 15 full-rate FMACs produce ALL twelve window sums of the symbol (on-time P1..P4, early
         // and late correlations of BOTH tones) as row partials in lanes t = lane & 15, with no product instructions, no
         // dominant-tone dependence and no v_readlane. One all-reduce over the four rows (two permlane swaps of the value
-        // with itself) completes them; v_mov_b64_dpp row_newbcast hands the numbers the loop filters need to every lane
-        // (one instruction per double instead of two v_readlane + the SGPR-operand restrictions), and the four early /
-        // late energies are formed lane-parallel (square, row_ror:8, add: Re at t, Im at t + 8) before they are handed out.
-        // 22 VALU instructions and all s_nop fewer per symbol than `symbol` (scripts/microbench/dpp64.hip has the
-        // instruction costs). Sections 3 onward are the ROLE 0 statements of `symbol`.
+        // with a copy of itself) completes them; v_mov_b64_dpp row_newbcast hands the numbers the loop filters need to
+        // every lane (one instruction per double instead of two v_readlane + the SGPR-operand restrictions), and the four
+        // early / late energies are formed lane-parallel (square, row_ror:8, add: Re at t, Im at t + 8), the dominant
+        // tone's pair selected lane-parallel (row_shl:2), before two of them are handed out. The phase detector's angle
+        // comes without the octant fix-up (opv_atan2.h: opv_atan2_q, 129-row table of pi/4 + atan, degree 7).
+        // Scheduling notes: hipcc counts an asm block as no wait state and pads the fp64 instruction behind one with an
+        // s_nop; every block here is therefore followed by a 32-bit instruction that was needed anyway, and the wait
+        // states DPP reads / permlane swaps need behind a VALU write are filled with useful instructions, not s_nop.
+        // (scripts/microbench/dpp64.hip has the instruction costs.)
         [[maybe_unused]] auto symbol_r = [&](auto tag, PrevSums& cur, const PrevSums& prv) {
             constexpr bool kFirst = decltype(tag)::first;
             constexpr bool kWide = decltype(tag)::wide;
@@ -812,40 +819,56 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             } else {
                 expj_small(kfs, fo, sck, xs, xc);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t my_soft_off = soft_off;
+            uint32_t soft_off_next = soft_off + 8u;                 // (32-bit filler behind the asm block above)
+            asm volatile("" : "+v"(soft_off_next));
+            __builtin_amdgcn_sched_barrier(0);
             const double zr = fma(lr, xc, li * xs);                         // Z = Lam * conj(X)
             const double zi = fma(li, xc, -(lr * xs));
             __builtin_amdgcn_sched_barrier(0);
 
-            // ---- 1. the twelve window sums: row partials by broadcast-FMAC (the two moves are the wait states a DPP
-            // read needs behind the VALU write of Z), two accumulators
-            double acc0, acc1;
-#define OPV_RB(N) "v_fmac_f64_dpp %0, %2, %[r" #N "] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t" \
-                  "v_fmac_f64_dpp %1, %3, %[i" #N "] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
-            asm("v_mov_b64 %0, 0\n\tv_mov_b64 %1, 0\n\t" OPV_RB(0) OPV_RB(1) OPV_RB(2) OPV_RB(3) OPV_RB(4) OPV_RB(5) OPV_RB(6) OPV_RB(7)
-                : "=&v"(acc0), "=&v"(acc1)
-                : "v"(zr), "v"(zi), [r0] "v"(wr[0]), [i0] "v"(wi[0]), [r1] "v"(wr[1]), [i1] "v"(wi[1]), [r2] "v"(wr[2]), [i2] "v"(wi[2]),
+            // ---- 1. the twelve window sums: row partials by broadcast-FMAC into two accumulators (the two moves are
+            // the wait states a DPP read needs behind the VALU write of Z)
+            double acc0, acc1, v, t;
+#define OPV_RB(N) "v_fmac_f64_dpp %[a0], %[zr], %[r" #N "] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t" \
+                  "v_fmac_f64_dpp %[a1], %[zi], %[i" #N "] row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+            asm("v_mov_b64 %[a0], 0\n\tv_mov_b64 %[a1], 0\n\t" OPV_RB(0) OPV_RB(1) OPV_RB(2) OPV_RB(3) OPV_RB(4) OPV_RB(5) OPV_RB(6) OPV_RB(7)
+                : [a0] "=&v"(acc0), [a1] "=&v"(acc1)
+                : [zr] "v"(zr), [zi] "v"(zi), [r0] "v"(wr[0]), [i0] "v"(wi[0]), [r1] "v"(wr[1]), [i1] "v"(wi[1]), [r2] "v"(wr[2]), [i2] "v"(wi[2]),
                   [r3] "v"(wr[3]), [i3] "v"(wi[3]), [r4] "v"(wr[4]), [i4] "v"(wi[4]), [r5] "v"(wr[5]), [i5] "v"(wi[5]),
                   [r6] "v"(wr[6]), [i6] "v"(wi[6]), [r7] "v"(wr[7]), [i7] "v"(wi[7]));
+            __builtin_amdgcn_sched_barrier(0);
+            soft_off = soft_off_next & soft_bmask;                  // (32-bit filler between the two blocks)
+            asm volatile("" : "+v"(soft_off));
+            __builtin_amdgcn_sched_barrier(0);
+            // second half, the sum of the two accumulators and the copy the all-reduce swaps with
             asm(OPV_RB(8) OPV_RB(9) OPV_RB(10) OPV_RB(11) OPV_RB(12) OPV_RB(13) OPV_RB(14)
-                : "+v"(acc0), "+v"(acc1)
-                : "v"(zr), "v"(zi), [r8] "v"(wr[8]), [i8] "v"(wi[8]), [r9] "v"(wr[9]), [i9] "v"(wi[9]), [r10] "v"(wr[10]), [i10] "v"(wi[10]),
+                "v_add_f64 %[v], %[a0], %[a1]\n\t"
+                "v_mov_b64 %[t], %[v]"
+                : [a0] "+v"(acc0), [a1] "+v"(acc1), [v] "=&v"(v), [t] "=&v"(t)
+                : [zr] "v"(zr), [zi] "v"(zi), [r8] "v"(wr[8]), [i8] "v"(wi[8]), [r9] "v"(wr[9]), [i9] "v"(wi[9]), [r10] "v"(wr[10]), [i10] "v"(wi[10]),
                   [r11] "v"(wr[11]), [i11] "v"(wi[11]), [r12] "v"(wr[12]), [i12] "v"(wi[12]), [r13] "v"(wr[13]), [i13] "v"(wi[13]),
                   [r14] "v"(wr[14]), [i14] "v"(wi[14]));
 #undef OPV_RB
             __builtin_amdgcn_sched_barrier(0);
-            cur.x40c = readlane_d(xc, 53);                          // sample 50 = X[40] sits in row 3, lane 5
-            cur.x40s = readlane_d(xs, 53);
-            double v = acc0 + acc1;
-            v = swap32_add(v, v);                                   // all-reduce over the four rows
-            v = swap16_add(v, v);
+            // ---- all-reduce over the four rows; the X[40] hand-over (sample 50 sits in row 3, lane 5) fills the two wait
+            // states a swap needs behind the copy
+            cur.x40c = readlane_d(xc, 53);
             __builtin_amdgcn_sched_barrier(0);
-            const double sq = v * v;
-            const uint32_t my_soft_off = soft_off;
-            soft_off = (soft_off + 8u) & soft_bmask;
-            asm volatile("" : "+v"(soft_off));
+            v = swap32_add(v, t);
+            asm("v_mov_b64 %0, %1" : "=v"(t) : "v"(v));
+            __builtin_amdgcn_sched_barrier(0);
+            cur.x40s = readlane_d(xs, 53);
+            __builtin_amdgcn_sched_barrier(0);
+            v = swap16_add(v, t);
+            __builtin_amdgcn_sched_barrier(0);
             double fo_sum_next = fo_sum + fo;                       // sum of the fo every symbol USED
             asm volatile("" : "+v"(fo_sum_next));
+            const double sq = v * v;
             __builtin_amdgcn_sched_barrier(0);
+            // on-time sums to every lane (v_mov_b64_dpp row_newbcast); the 32-bit row_ror:8 moves behind the block keep
+            // hipcc from padding it
             double P1o, P2o, P3o, P4o;
             asm("v_mov_b64_dpp %0, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
                 "v_mov_b64_dpp %1, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -853,67 +876,81 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 "v_mov_b64_dpp %3, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf"
                 : "=&v"(P1o), "=&v"(P2o), "=&v"(P3o), "=&v"(P4o) : "v"(v));
             __builtin_amdgcn_sched_barrier(0);
-            // energies of the early / late correlations, lane-parallel: t = 4..7 -> |E_1|^2, |E_2|^2, |L_1|^2, |L_2|^2
-            const double sh = mkd(__builtin_amdgcn_mov_dpp(dhi(sq), 0x128, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(dlo(sq), 0x128, 0xF, 0xF, true));
-            const double en = sq + sh;
+            // energies of the early / late correlations, lane-parallel (Re at t, Im at t + 8): t = 4..7 -> |E_1|^2, |L_1|^2,
+            // |E_2|^2, |L_2|^2
+            const double shv = mkd(__builtin_amdgcn_mov_dpp(dhi(v), 0x128, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(dlo(v), 0x128, 0xF, 0xF, true));
             __builtin_amdgcn_sched_barrier(0);
             const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;        // S_1 (tone -13550)
+            const double en = fma(shv, shv, sq);
             const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;        // S_2 (tone +13550)
             const double en1 = fma(s1r_, s1r_, s1i_ * s1i_);        // ref :264-265
             const double en2 = fma(s2r_, s2r_, s2i_ * s2i_);
             const double soft = en2 - en1;                          // ref :268
-            nsg = mkd((dhi(soft) & (int)0x80000000) | 0x3ff00000, dlo(nsg));
-            const double sg = -nsg;
             __builtin_amdgcn_sched_barrier(0);
-            double EE1, EE2, LL1, LL2;
-            asm("v_mov_b64_dpp %0, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-                "v_mov_b64_dpp %1, %4 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-                "v_mov_b64_dpp %2, %4 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-                "v_mov_b64_dpp %3, %4 row_newbcast:7 row_mask:0xf bank_mask:0xf"
-                : "=&v"(EE1), "=&v"(EE2), "=&v"(LL1), "=&v"(LL2) : "v"(en));
-            const bool dom1 = soft < 0.0;                           // ref :272 / :291 (a tie gives +0: tone 2)
-            const double ee = dom1 ? EE1 : EE2, el = dom1 ? LL1 : LL2;
-            const double num = el - ee, den = el + ee + kc_eps;     // ted = num/den (ref :275/:279)
+            // the dominant tone's pair moves to t = 4, 5 (row_shl:2 brings tone 2's over), then one hand-out each;
+            // tone 1 iff e1 > e2 (ref :272 / :291; a tie gives +0: tone 2). sg = +1 for tone 1, -1 for tone 2.
+            const bool dom1 = soft < 0.0;
+            nsg = mkd((dhi(soft) & (int)0x80000000) | (dhi(nsg) & 0x7fffffff), dlo(nsg));
+            const double sg = -nsg;
+            const double oth = mkd(__builtin_amdgcn_mov_dpp(dhi(en), 0x102, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(dlo(en), 0x102, 0xF, 0xF, true));
+            __builtin_amdgcn_sched_barrier(0);
+            const double seln = dom1 ? en : oth;
+            __builtin_amdgcn_sched_barrier(0);
 
-            double ted = 0, pd = 0.0;
-            double dr = 0, di = 0, cx = 0, cy = 0, ax = 0, ay = 0, mx = 1.0, mn = 0, ratio = 0, dm_ = 1.0;
-            double2 c01{0, 0}, c23{0, 0}, c45{0, 0}, c67{0, 0};
-            double c8 = 0, h = 0;
+            [[maybe_unused]] double pd = 0.0, cx = 0, cy = 0, sum = 1.0, dif = 0, dm_ = 1.0, ee, el;
             if constexpr (!kFirst) {
                 // phase detector operands: dom * conj(prev) (ref :299), see `symbol`
-                dr = fma(sg, P2o, P1o);
-                di = fma(-sg, P4o, P3o);
+                const double dr = fma(sg, P2o, P1o), di = fma(-sg, P4o, P3o);
                 const double prs = fma(sg, prv.a, prv.b), pis = fma(sg, prv.c, -prv.d);
                 const double ar = fma(dr, prs, di * pis), ai = fma(di, prs, -(dr * pis));
                 cy = fma(ar, prv.x40c, ai * prv.x40s);              // Im z
                 cx = fma(ar, prv.x40s, -(ai * prv.x40c));           // Re z
-                ax = fabs(cx); ay = fabs(cy);
-                asm("v_max_f64 %0, |%3|, |%4|\n\tv_min_f64 %1, |%3|, |%4|\n\tv_max_f64 %2, %0, %5"
-                    : "=&v"(mx), "=&v"(mn), "=&v"(dm_) : "v"(cx), "v"(cy), "v"(kc_tiny));
+                __builtin_amdgcn_sched_barrier(0);
+                asm("v_mov_b64_dpp %0, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"      // hand-outs of the two energies
+                    "v_mov_b64_dpp %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf"
+                    : "=&v"(ee), "=&v"(el) : "v"(seln));
+                __builtin_amdgcn_sched_barrier(0);
+                // cx < 0: pi - pd, as a +/-1 multiplier and a 0/pi offset built from the sign bit
+                sx = mkd((dhi(cx) & (int)0x80000000) | (dhi(sx) & 0x7fffffff), dlo(sx));
+                asm volatile("" : "+v"(sx));
+                __builtin_amdgcn_sched_barrier(0);
+                sum = fabs(cx) + fabs(cy); dif = fabs(cy) - fabs(cx);
+                dm_ = fmax(sum, kc_tiny);
+            } else {
+                asm("s_nop 1\n\t"                                   // (the select's two wait states; once per demodulate() call)
+                    "v_mov_b64_dpp %0, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                    "v_mov_b64_dpp %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf"
+                    : "=&v"(ee), "=&v"(el) : "v"(seln));
             }
+            const double den = el + ee + kc_eps;                    // ted = num/den (ref :275/:279)
 
-            // ---- 3. divides, timing loop, AFC: as in `symbol` -----------------------------------------
+            // ---- 3. divides (one reciprocal for both), timing loop, AFC --------------------------------
+            double ted, h = 0;
+            [[maybe_unused]] double2 c01{0, 0}, c23{0, 0}, c45{0, 0}, c67{0, 0};
             if constexpr (kFirst) {
                 double y = __builtin_amdgcn_rcp(den);
+                const double num = el - ee;
                 y = fma(fma(-den, y, 1.0), y, y);
                 y = fma(fma(-den, y, 1.0), y, y);
                 ted = num * y;
                 ted = fma(fma(-den, ted, num), y, ted);
             } else {
-                const double dm = dm_;
+                const double dm = dm_;                              // max(|cx| + |cy|, 1e-100); digital silence: 0/1e-100 = 0, fixed up below
                 const double tt = den * dm;
                 double y = __builtin_amdgcn_rcp(tt);
-                y = fma(fma(-tt, y, 1.0), y, y);
+                const double num = el - ee;                         // (fills the wait state behind the reciprocal)
+                // ONE Newton step: v_rcp_f64 is good to 2^-24.4, one step to 2^-48.7, and both quotients below get their
+                // own residual step - the same error profile as with two (scripts/microbench/rcp_accuracy.hip)
                 y = fma(fma(-tt, y, 1.0), y, y);
                 const double iden = y * dm, idm = y * den;
-                ratio = mn * idm;
-                ratio = fma(fma(-dm, ratio, mn), idm, ratio);
-                const double kd = rint(ratio * kc_32);
+                double ratio = dif * idm;                           // q = (|cy| - |cx|) / (|cy| + |cx|) in [-1, 1]
+                ratio = fma(fma(-dm, ratio, dif), idm, ratio);
+                const double kd = rint(ratio * kc_64);              // nearest expansion point k/64, k = -64..64
                 const int k = (int)kd;
-                h = fma(kd, kc_m1_32, ratio);
-                const unsigned char* rowb = reinterpret_cast<const unsigned char*>(atab) + __umul24((unsigned)k, kTabRow * 8u);
+                h = fma(kd, kc_m1_64, ratio);                       // |h| <= 1/128
+                const unsigned char* rowb = reinterpret_cast<const unsigned char*>(atab) + 64 * 64 + k * 64;
                 const double2* trow = reinterpret_cast<const double2*>(rowb);
-                c8 = reinterpret_cast<const double*>(rowb)[8]; c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
+                c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
                 ted = num * iden;
                 ted = fma(fma(-den, ted, num), iden, ted);
             }
@@ -923,27 +960,25 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             pos += 40.0 + adj;                                        // ref :313
             fetch_addr(pos, false);
             __builtin_amdgcn_sched_barrier(0);
-            fetch_read();
+            fetch_read();                                             // next symbol's taps requested as soon as their address exists
             __builtin_amdgcn_sched_barrier(0);
             *(gdouble*)(soft_base + my_soft_off) = soft;
             if constexpr (!kFirst) {
-                sx = mkd((dhi(cx) & (int)0x80000000) | 0x3ff00000, dlo(sx));
                 const double pd_off = fma(-sx, kc_halfpi, kc_halfpi);
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0xC17F);                 // lgkmcnt(1): the table row landed
+                __builtin_amdgcn_s_waitcnt(0xC17F);                 // lgkmcnt(1): the table row landed (only the tap read may be in flight)
                 __builtin_amdgcn_sched_barrier(0);
-                pd = fma(c8, h, c67.y);                             // degree-8 Horner
-                pd = fma(pd, h, c67.x);
+                pd = fma(c67.y, h, c67.x);                          // degree-7 Horner: pi/4 + atan(q)
                 pd = fma(pd, h, c45.y);
                 pd = fma(pd, h, c45.x);
                 pd = fma(pd, h, c23.y);
                 pd = fma(pd, h, c23.x);
                 pd = fma(pd, h, c01.y);
                 pd = fma(pd, h, c01.x);
-                pd = (ay > ax) ? kc_halfpi - pd : pd;               // octant fix-up
                 pd = fma(sx, pd, pd_off);
                 pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));  // sign of cy
-                if (__builtin_expect(uni_eq(mx, 0.0), 0)) {         // digital silence on either side
+                if (__builtin_expect(uni_eq(sum, 0.0), 0)) {        // digital silence on either side
+                    const double dr = fma(sg, P2o, P1o), di = fma(-sg, P4o, P3o);
                     const double2 sp = silence_pd(dr, di, prv, soft < 0.0, fo_sum, n_soft + (((my_soft_off - soft_off0) & soft_bmask) >> 3),
                                                   P1o, P2o, P3o, P4o);
                     pd = sp.x;
@@ -1052,17 +1087,22 @@ extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_wg4(OpvStream* 
     msk_frontend_body<4, 0>(streams, cfg, n_streams, lds_all);
 }
 // the same two launch shapes with the row-broadcast reduction (msk_frontend_body<.., 0, true>, `symbol_r`)
+template <int NT>
+__device__ __forceinline__ void load_atan_table_q(unsigned char* lds_tab) {
+    double* atab = reinterpret_cast<double*>(lds_tab);
+    for (int i = threadIdx.x; i < 129 * 8; i += NT) atab[i] = (&kOpvAtanTabQ[0][0])[i];
+}
 extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_rb(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
                                                                     int n_streams) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[kTabOff + 33 * kTabRow * 8];
-    load_atan_table<64>(lds_all + kTabOff);
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[kTabOff + 129 * 64];
+    load_atan_table_q<64>(lds_all + kTabOff);
     __syncthreads();
     msk_frontend_body<1, 0, true>(streams, cfg, n_streams, lds_all);
 }
 extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_rb_wg4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
                                                                          int n_streams) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * kTabOff + 33 * kTabRow * 8];
-    load_atan_table<256>(lds_all + 4 * kTabOff);
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * kTabOff + 129 * 64];
+    load_atan_table_q<256>(lds_all + 4 * kTabOff);
     __syncthreads();
     msk_frontend_body<4, 0, true>(streams, cfg, n_streams, lds_all);
 }

@@ -25,8 +25,11 @@ __global__ void k_check(double* out) {
 #undef STEP
     double m;
     asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "=v"(m) : "v"(acc));
+    double m1;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:5 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(m1) : "v"(acc));
     out[l] = acc;
     out[64 + l] = m;
+    out[128 + l] = m1;
 }
 
 // 16 bcast-FMACs into ONE accumulator (dependent chain), REP times
@@ -136,10 +139,10 @@ static void run(const char* name, K k, int per_rep, int rep = 4000) {
 }
 
 int main() {
-    double* d; CK(hipMalloc(&d, 128 * 8));
+    double* d; CK(hipMalloc(&d, 192 * 8));
     k_check<<<1, 64>>>(d);
-    std::vector<double> h(128);
-    CK(hipMemcpy(h.data(), d, 128 * 8, hipMemcpyDeviceToHost));
+    std::vector<double> h(192);
+    CK(hipMemcpy(h.data(), d, 192 * 8, hipMemcpyDeviceToHost));
     int bad = 0;
     for (int l = 0; l < 64; ++l) {
         double ref = 0; const int row = l / 16;
@@ -147,6 +150,9 @@ int main() {
         if (std::fabs(ref - h[l]) > 1e-9 * std::fabs(ref)) ++bad;
     }
     for (int l = 0; l < 64; ++l) if (h[64 + l] != h[(l / 16) * 16 + 5]) ++bad;
+    int bc = 0;
+    for (int l = 0; l < 64; ++l) if (h[128 + l] != h[(l / 16) * 16 + 5]) ++bc;
+    printf("v_mov_b64_dpp row_newbcast with bound_ctrl:1: %s (%d lanes differ from the broadcast)\n", bc ? "NOT a broadcast" : "same as without", bc);
     printf("semantics: %s\n", bad ? "MISMATCH" : "ok (fmac: dst += src0[row lane n] * src1[own lane]; mov: dst = src0[row lane n])");
     run("v_fmac_f64 plain, dependent", k_fmac_plain, 16);
     run("v_fmac_f64_dpp, dependent", k_fmac_dpp_dep, 16);
