@@ -151,9 +151,11 @@ int opv_sync(opv_ctx* ctx);
 /* Stream-to-wavefront mapping of the front-end kernel (no counterpart in the reference, which is one thread
  * per process): 1 = one wavefront per stream (lowest per-symbol latency; right while the GPU has idle SIMDs),
  * 4 = four streams per wavefront (fewest issued instructions per symbol; right when every SIMD has work),
- * -2 = TWO wavefronts per stream, one per feedback loop (experimental: exact, but 6 % slower than 1 today; never automatic),
- * 0 = automatic (4 from 4096 streams per context; measured cross-over on MI355X). Results do not depend on the mapping beyond the fp64
- * re-association level of the soft symbols (all decisions identical; tests run both). */
+ * 0 = automatic (4 from 4096 streams per context; measured cross-over on MI355X).
+ * Kept for comparison, never automatic: -1 = one wavefront per stream with the product + permlane-swap reductions
+ * (the default until the row-broadcast reduction replaced it: 1041 against 880 cycles per symbol), -2 = TWO wavefronts
+ * per stream, one per feedback loop (exact, 6 % slower than -1). Results do not depend on the mapping beyond the
+ * fp64 re-association level of the soft symbols (all decisions identical; the tests run every mapping). */
 int opv_set_frontend(opv_ctx* ctx, int streams_per_wave);
 /* Restores a stream (stream = -1: every stream) to its freshly-created state (keeps buffers). */
 int opv_reset_stream(opv_ctx* ctx, int stream);

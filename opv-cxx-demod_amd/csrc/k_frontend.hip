@@ -259,7 +259,7 @@ __device__ inline void role_await(uint32_t a, uint32_t want, double& v, uint32_t
 // bits), every statement below that belongs to the other loop is compiled out, and at the end of a symbol T publishes
 // pos(k+1), F publishes fo(k+1); each waits for the other's number where it first needs it. Tile staging is T's; its
 // events keep one symbol more margin so that F, at most one symbol behind, never reads a tile that has not landed or has
-// been recycled. STATUS: exact (tests/test_gpu_parity.py::test_two_waves_per_stream_mapping_is_exact) but 6 % SLOWER than
+// been recycled. STATUS: exact (tests/test_gpu_parity.py::test_comparison_mappings_are_exact) but 6 % SLOWER than
 // ROLE 0 (1111 vs 1043 cycles per symbol at 64 streams): each wave's LDS round trips and cross-lane hazard slots are no
 // longer filled by the other loop's arithmetic, and the partner is waited for once per symbol. It is
 // never selected automatically (opv_set_frontend(ctx, -2)).

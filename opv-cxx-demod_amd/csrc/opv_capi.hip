@@ -52,8 +52,8 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
     } while (0)
 
 // one wave per stream, four of them per workgroup: from the stream count at which single-wave workgroups start to
-// double up on SIMDs (k_frontend.hip: msk_frontend_body) up to the count its two workgroups per CU (LDS) can hold at once
-constexpr int kFrontendWg4MinStreams = 512, kFrontendWg4MaxStreams = 2048;
+// double up on SIMDs (k_frontend.hip: msk_frontend_body)
+constexpr int kFrontendWg4MinStreams = 512;
 constexpr int kFrontendX4Wg4MaxStreams = 8192;   // 2048 waves = two 80 KB workgroups per CU; beyond that single-wave workgroups (20 KB)
 constexpr int kFrontendX4MinStreams = 4096;      // measured cross-over on MI355X: front-end alone 118 vs 110 GS/s at 4096 streams, 130 vs 111 at 6144
 
@@ -140,7 +140,7 @@ struct opv_ctx {
     double tx_ph1 = 0.0, tx_ph2 = 0.0;   // phases after the last cached symbol
     double* d_tx_phases = nullptr;
     size_t d_tx_phases_cap = 0;          // symbols
-    int frontend = 0;  // 0: by stream count, 1: one wave per stream, 4: four streams per wave (opv_set_frontend)
+    int frontend = 0;  // 0: by stream count, 1: one wave per stream, 4: four streams per wave, -1 / -2: see opv_set_frontend
     bool timing = false;
     bool timing_valid = false;
     hipEvent_t ev[8] = {};
@@ -462,15 +462,16 @@ extern "C" int opv_process(opv_ctx* c) {
         k_coherent_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, 2.0 * zeta * wn / fsym, wn * wn / (fsym * fsym));
     } else if (c->frontend == -2) {                        // two waves per stream (opv_set_frontend(-2))
         k_msk_frontend_dual<<<S, 128, 0, c->stream>>>(c->d_streams, g, S);
-    } else if (c->frontend == -3) {                        // one wave per stream, row-broadcast reduction (opv_set_frontend(-3))
-        if (S > kFrontendWg4MinStreams) k_msk_frontend_rb_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);
-        else k_msk_frontend_rb<<<S, 64, 0, c->stream>>>(c->d_streams, g, S);
+    } else if (c->frontend == -1) {                        // one wave per stream, product + swap reductions (the round-1 body)
+        if (S > kFrontendWg4MinStreams) k_msk_frontend_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);
+        else k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g, S);
     } else if (x4 && S <= kFrontendX4Wg4MaxStreams)        // up to two waves per SIMD: four waves (16 streams) per workgroup
         k_msk_frontend_x4_wg4<<<(S + 15) / 16, 256, 0, c->stream>>>(c->d_streams, g, S);
     else if (x4) k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
-    else if (S > kFrontendWg4MinStreams && S <= kFrontendWg4MaxStreams)
-        k_msk_frontend_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);
-    else k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g, S);
+    // one wave per stream, row-broadcast reduction (k_frontend.hip: symbol_r). Its 281 registers allow one wave per SIMD;
+    // four waves per workgroup (one per SIMD of a CU by construction) as soon as single-wave workgroups could double up
+    else if (S > kFrontendWg4MinStreams) k_msk_frontend_rb_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);
+    else k_msk_frontend_rb<<<S, 64, 0, c->stream>>>(c->d_streams, g, S);
     if (tm) { HIPCHK(hipEventRecord(c->ev[3], c->stream)); HIPCHK(hipEventRecord(c->ev[4], c->stream)); }
     k_sync_track<<<S, 64, 0, c->stream>>>(c->d_streams);
     if (tm) { HIPCHK(hipEventRecord(c->ev[5], c->stream)); HIPCHK(hipEventRecord(c->ev[6], c->stream)); }
@@ -487,8 +488,8 @@ extern "C" int opv_process(opv_ctx* c) {
 
 extern "C" int opv_set_frontend(opv_ctx* c, int streams_per_wave) {
     if (!c) return fail(OPV_EINVAL, "null context");
-    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4 && streams_per_wave != -2 && streams_per_wave != -3)
-        return fail(OPV_EINVAL, "opv_set_frontend: 0 (automatic), 1 or 4 streams per wave, -2 = two waves per stream");
+    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4 && streams_per_wave != -1 && streams_per_wave != -2)
+        return fail(OPV_EINVAL, "opv_set_frontend: 0 (automatic), 1 or 4 streams per wave, -1 = one wave per stream with the product + swap reductions, -2 = two waves per stream");
     c->frontend = streams_per_wave;
     return OPV_OK;
 }

@@ -172,7 +172,7 @@ class Demod:
                        device, int(coherent), int(max_samples), float(pll_bw))
         self.h = C.c_void_p()
         _chk(lib().opv_create(C.byref(self.h), n_streams, C.byref(self.cfg)))
-        if os.environ.get("OPV_FRONTEND"):      # dev switch: run everything on one mapping (0 / 1 / 4)
+        if os.environ.get("OPV_FRONTEND"):      # dev switch: run everything on one mapping (0 / 1 / 4 / -1 / -2)
             self.set_frontend(int(os.environ["OPV_FRONTEND"]))
 
     def close(self):

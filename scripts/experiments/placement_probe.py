@@ -18,7 +18,7 @@ iq = amd.modulate(amd.bert_frames(F))
 n = iq.size // 2
 d_iq = torch.from_numpy(iq).cuda()
 d = amd.Demod(S, max_samples=n + 64, streaming=True)
-d.set_frontend(1)
+d.set_frontend(int(sys.argv[4]) if len(sys.argv) > 4 else 1)
 d.enable_timing(True)
 for rep in range(reps):
     d.reset()

@@ -1,4 +1,4 @@
-"""dev: one noisy, frequency-shifted stream through the one-wave front-end (mode 1) and the row-broadcast variant (mode -3):
+"""dev: one noisy, frequency-shifted stream through the one-wave front-end (product + swap reductions, mode -1) and the row-broadcast variant (mode 1):
 first soft symbol / chunk-log entry where they differ, and by how much."""
 import sys
 from pathlib import Path
@@ -15,17 +15,17 @@ n = iq.size // 2
 d_clean = torch.from_numpy(iq).cuda()
 d_iq = torch.empty_like(d_clean)
 out = {}
-for mode in (1, -3):
+for mode in (-1, 1):
     d = amd.Demod(1, max_samples=n + 64, streaming=True)
     d.set_frontend(mode)
-    if mode == 1:
+    if mode == -1:
         d.channel(d_clean.data_ptr(), d_iq.data_ptr(), n, gain=1.0, f0_hz=f0, sigma=sigma, seed=5)
         d.sync()
     d.attach(0, d_iq.data_ptr(), n, eof=True)
     d.process(); d.sync()
     out[mode] = (np.array(d.soft(0)), np.array(d.chunks(0)), d.pop_frames(0)[0])
     d.close()
-a, b = out[1], out[-3]
+a, b = out[-1], out[1]
 print("symbols", len(a[0]), len(b[0]), "chunks", a[1].shape, b[1].shape, "frames", len(a[2]), len(b[2]))
 m = min(len(a[0]), len(b[0]))
 rel = np.abs(a[0][:m] - b[0][:m]) / (np.abs(a[0][:m]).mean() + 1e-300)

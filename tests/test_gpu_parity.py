@@ -158,22 +158,25 @@ def test_afc_alpha_flag(amd, oracle, iq10):
     d.close()
 
 
-def test_two_waves_per_stream_mapping_is_exact(amd, oracle, iq10, iq100):
-    """opv_set_frontend(-2): the timing loop and the AFC on two wavefronts that exchange pos / fo through LDS every
-    symbol (k_msk_frontend_dual = ROLE 1 / 2 of csrc/k_frontend.hip's body; not selected automatically). Same bar as the other mappings: clean, offset + noise,
-    an out-of-range -o, ragged lengths, -s and batch, several streams in one context."""
+@pytest.mark.parametrize("mapping", [-2, -1])
+def test_comparison_mappings_are_exact(amd, oracle, iq10, iq100, mapping):
+    """The two one-stream mappings kept for comparison, never selected automatically. opv_set_frontend(-2): the timing loop
+    and the AFC on two wavefronts that exchange pos / fo through LDS every symbol (k_msk_frontend_dual = ROLE 1 / 2 of
+    csrc/k_frontend.hip's body). opv_set_frontend(-1): one wavefront per stream with the product + permlane-swap reductions
+    (`symbol`; the default mapping 1 is the row-broadcast reduction `symbol_r`). Same bar as the other mappings: clean,
+    offset + noise, an out-of-range -o, ragged lengths, -s and batch, several streams in one context."""
     caps = [iq10, impair(iq10, amp=3000.0, f0_hz=-1700.0, ebn0_db=9.0, seed=3), impair(iq100[: 2 * 40 * 86720], amp=2000.0, f0_hz=900.0, ebn0_db=14.0, seed=8),
             iq10[: 2 * 123457], iq10[: 2 * 86719], np.zeros(2 * 90000, np.int16)]
     for streaming in (True, False):
         d = amd.Demod(len(caps), max_samples=max(c.size for c in caps) // 2 + 64, streaming=streaming)
-        d.set_frontend(-2)
+        d.set_frontend(mapping)
         got = d.receive(caps)
         d.close()
         for k, x in enumerate(caps):
-            check_stream(amd, got[k], oracle.receive(x, streaming=streaming), f"dual stream {k} streaming={streaming}")
+            check_stream(amd, got[k], oracle.receive(x, streaming=streaming), f"mapping {mapping} stream {k} streaming={streaming}")
     d = amd.Demod(1, max_samples=iq10.size // 2 + 64, streaming=True, init_offset=150000.0, afc_alpha=0.01)
-    d.set_frontend(-2)
-    check_stream(amd, d.receive([iq10])[0], oracle.receive(iq10, streaming=True, init_offset=150000.0, afc_alpha=0.01), "dual -o 150000")
+    d.set_frontend(mapping)
+    check_stream(amd, d.receive([iq10])[0], oracle.receive(iq10, streaming=True, init_offset=150000.0, afc_alpha=0.01), f"mapping {mapping} -o 150000")
     d.close()
 
 
