@@ -112,6 +112,11 @@ __device__ inline double dpp_add(double v) {
     const int hi = __builtin_amdgcn_mov_dpp(dhi(v), CTRL, 0xF, 0xF, true);
     return v + mkd(hi, lo);
 }
+// v_mov_b64_dpp row_newbcast:N - lane N of every row of 16 to all lanes of that row (the one DPP control 64-bit operations
+// take). Through the builtin, so that hipcc sees the DPP hazards and schedules around them; every lane is written, `old`
+// only names the register: pass a dead value (a zero or an undefined one would cost a move or an s_nop).
+template <int N>
+__device__ inline double row_bcast(double old, double v) { return __builtin_amdgcn_update_dpp(old, v, 0x150 + N, 0xF, 0xF, false); }
 __device__ inline uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ inline double readlane_d(double v, int l) {
     return mkd(__builtin_amdgcn_readlane(dhi(v), l), __builtin_amdgcn_readlane(dlo(v), l));
@@ -295,27 +300,31 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         if (lane >= 10 && lane < 50) { sincospi((double)(lane - 10) / 80.0, &sn, &cs); aO = cs; bO = -sn; }
         if (lane >= 20 && lane < 60) { sincospi((double)(lane - 20) / 80.0, &sn, &cs); aL = cs; bL = -sn; }
     }
-    // RMAC: output t = lane & 15 of every row is one of the symbol's twelve window sums, and wr[n] / wi[n] are the
-    // weights of Re / Im Z of the row's n-th sample in it (see `symbol_r`):
-    //   t = 0..3   on-time P1 = sum Zr a, P2 = sum Zi b, P3 = sum Zi a, P4 = sum Zr b        (window j in [10, 50), i = j - 10)
-    //   t = 4..7   Re of the early / late correlation of tone 1, then of tone 2 (E_1, L_1, E_2, L_2); t = 12..15 their Im
-    //              (early: j in [0, 40), i = j; late: j in [20, 60), i = j - 20)
-    //   C_1 = sum Z conj(T_1[i]) = (sum Zr a + Zi b, sum Zi a - Zr b), C_2 = sum Z T_1[i] = (sum Zr a - Zi b, sum Zi a + Zr b)
+    // RMAC: output t = lane & 15 of every row is one of the symbol's window sums, and wr[n] / wi[n] are the weights of
+    // Re / Im Z of the row's n-th sample in it (see `symbol_r`). Correlations C_1 = sum Z conj(T_1[i]) = (sum Zr a + Zi b,
+    // sum Zi a - Zr b), C_2 = sum Z T_1[i] = (sum Zr a - Zi b, sum Zi a + Zr b); Re in t, Im in t + 8:
+    //   t = 0, 1   on-time correlation of tone 1 / tone 2 (S_1, S_2)                          (window j in [10, 50), i = j - 10)
+    //   t = 2..5   early / late correlation of tone 1, then of tone 2 (E_1, L_1, E_2, L_2)    (early: j in [0, 40), i = j;
+    //                                                                                           late: j in [20, 60), i = j - 20)
+    //   t = 6, 7, 14, 15   the on-time sums P1 = sum Zr a, P2 = sum Zi b, P3 = sum Zi a, P4 = sum Zr b
+    //              (S_1 = (P1 + P2, P3 - P4), S_2 = (P1 - P2, P3 + P4): what the phase detector and the carry use)
     [[maybe_unused]] double wr[15], wi[15];
     if constexpr (RMAC) {
-        const int row = lane >> 4, t = lane & 15;
-        const int gate = t < 4 ? 1 : ((t & 1) ? 2 : 0);          // 0 early, 1 on-time, 2 late
+        const int row = lane >> 4, t = lane & 15, u = t & 7;
+        const bool is_p = u >= 6, imag = t >= 8;
+        const int gate = (u < 2 || is_p) ? 1 : ((u & 1) ? 2 : 0);  // 0 early, 1 on-time, 2 late (u = 2: E_1, 3: L_1, 4: E_2, 5: L_2)
+        const bool tone2 = is_p ? false : (u < 2 ? u == 1 : u >= 4);
 #pragma unroll
         for (int n = 0; n < 15; ++n) {
             const int i = 15 * row + n - 10 * gate;
             double sn, cs;
             sincospi((double)i / 80.0, &sn, &cs);
-            const bool in = i >= 0 && i < 40 && !(t >= 8 && t < 12);
+            const bool in = i >= 0 && i < 40;
             const double a = in ? cs : 0.0, b = in ? -sn : 0.0;
             double r_, i_;
-            if (t < 4) { r_ = (t == 0) ? a : (t == 3 ? b : 0.0); i_ = (t == 1) ? b : (t == 2 ? a : 0.0); }
-            else if (t < 8) { r_ = a; i_ = (t & 2) ? -b : b; }    // Re C_1 / C_2
-            else { r_ = (t & 2) ? b : -b; i_ = a; }               // Im C_1 / C_2
+            if (is_p) { r_ = (t == 6) ? a : (t == 15 ? b : 0.0); i_ = (t == 7) ? b : (t == 14 ? a : 0.0); }   // P1, P4 | P2, P3
+            else if (!imag) { r_ = a; i_ = tone2 ? -b : b; }      // Re C_1 / C_2
+            else { r_ = tone2 ? b : -b; i_ = a; }                 // Im C_1 / C_2
             wr[n] = r_; wi[n] = i_;
             asm volatile("" : "+v"(wr[n]), "+v"(wi[n]));
         }
@@ -330,7 +339,6 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     double kc_tfmax = 0.1, kc_beta = 0.00001, kc_alpha = 0.005, kc_fomax = 2000.0, kc_eps = 1e-10;
     double kc_tiny = 1e-100;
     asm volatile("" : "+v"(kc_tiny));
-    if constexpr (RMAC) kc_tiny = __builtin_canonicalize(kc_tiny);   // (symbol_r uses it through fmax)
     double kc_halfpi = 1.57079632679489661923, kc_32 = 32.0, kc_m1_32 = -1.0 / 32.0, kc_gain = st.afc_alpha * (kSymRate / kTwoPi);
     [[maybe_unused]] double kc_64 = 64.0, kc_m1_64 = -1.0 / 64.0;
     asm volatile("" : "+v"(kc_64), "+v"(kc_m1_64));
@@ -867,34 +875,28 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             asm volatile("" : "+v"(fo_sum_next));
             const double sq = v * v;
             __builtin_amdgcn_sched_barrier(0);
-            // on-time sums to every lane (v_mov_b64_dpp row_newbcast); the 32-bit row_ror:8 moves behind the block keep
-            // hipcc from padding it
-            double P1o, P2o, P3o, P4o;
-            asm("v_mov_b64_dpp %0, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-                "v_mov_b64_dpp %1, %4 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-                "v_mov_b64_dpp %2, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-                "v_mov_b64_dpp %3, %4 row_newbcast:3 row_mask:0xf bank_mask:0xf"
-                : "=&v"(P1o), "=&v"(P2o), "=&v"(P3o), "=&v"(P4o) : "v"(v));
-            __builtin_amdgcn_sched_barrier(0);
-            // energies of the early / late correlations, lane-parallel (Re at t, Im at t + 8): t = 4..7 -> |E_1|^2, |L_1|^2,
-            // |E_2|^2, |L_2|^2
+            // energies, lane-parallel (Re at t, Im at t + 8): t = 0..5 -> |S_1|^2, |S_2|^2 (on-time), |E_1|^2, |L_1|^2, |E_2|^2, |L_2|^2
             const double shv = mkd(__builtin_amdgcn_mov_dpp(dhi(v), 0x128, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(dlo(v), 0x128, 0xF, 0xF, true));
-            __builtin_amdgcn_sched_barrier(0);
-            const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;        // S_1 (tone -13550)
             const double en = fma(shv, shv, sq);
-            const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;        // S_2 (tone +13550)
-            const double en1 = fma(s1r_, s1r_, s1i_ * s1i_);        // ref :264-265
-            const double en2 = fma(s2r_, s2r_, s2i_ * s2i_);
-            const double soft = en2 - en1;                          // ref :268
             __builtin_amdgcn_sched_barrier(0);
-            // the dominant tone's pair moves to t = 4, 5 (row_shl:2 brings tone 2's over), then one hand-out each;
+            // on-time sums P1..P4 to every lane (`old` operands: dead temporaries of the stages above)
+            const double P1o = row_bcast<6>(zr, v), P2o = row_bcast<7>(zi, v), P3o = row_bcast<14>(lr, v), P4o = row_bcast<15>(li, v);
+            __builtin_amdgcn_sched_barrier(0);
+            // soft value = |S_2|^2 - |S_1|^2 (ref :264-268): the difference of the two energies like the reference, each from its
+            // own correlation. (Where the reference's tones tie exactly - a real or imaginary Z - so do these: the two
+            // correlations' accumulation chains are mirror images.)
+            const double en1 = row_bcast<0>(acc0, en), en2 = row_bcast<1>(acc1, en);   // (behind the four hand-outs above: en's wait states)
+            const double soft = en2 - en1;
+            __builtin_amdgcn_sched_barrier(0);
+            // the dominant tone's early / late pair moves to t = 2, 3 (row_shl:2 brings tone 2's over), then one hand-out each;
             // tone 1 iff e1 > e2 (ref :272 / :291; a tie gives +0: tone 2). sg = +1 for tone 1, -1 for tone 2.
             const bool dom1 = soft < 0.0;
             nsg = mkd((dhi(soft) & (int)0x80000000) | (dhi(nsg) & 0x7fffffff), dlo(nsg));
             const double sg = -nsg;
             const double oth = mkd(__builtin_amdgcn_mov_dpp(dhi(en), 0x102, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(dlo(en), 0x102, 0xF, 0xF, true));
             __builtin_amdgcn_sched_barrier(0);
-            const double seln = dom1 ? en : oth;
+            double seln = dom1 ? en : oth;
+            asm volatile("" : "+v"(seln));                          // (the select stays here: the phase detector's arithmetic below is its two wait states)
             __builtin_amdgcn_sched_barrier(0);
 
             [[maybe_unused]] double pd = 0.0, cx = 0, cy = 0, sum = 1.0, dif = 0, dm_ = 1.0, ee, el;
@@ -906,21 +908,17 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 cy = fma(ar, prv.x40c, ai * prv.x40s);              // Im z
                 cx = fma(ar, prv.x40s, -(ai * prv.x40c));           // Re z
                 __builtin_amdgcn_sched_barrier(0);
-                asm("v_mov_b64_dpp %0, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"      // hand-outs of the two energies
-                    "v_mov_b64_dpp %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf"
-                    : "=&v"(ee), "=&v"(el) : "v"(seln));
+                ee = row_bcast<2>(sq, seln); el = row_bcast<3>(shv, seln);   // hand-outs of the two energies
                 __builtin_amdgcn_sched_barrier(0);
                 // cx < 0: pi - pd, as a +/-1 multiplier and a 0/pi offset built from the sign bit
                 sx = mkd((dhi(cx) & (int)0x80000000) | (dhi(sx) & 0x7fffffff), dlo(sx));
                 asm volatile("" : "+v"(sx));
-                __builtin_amdgcn_sched_barrier(0);
                 sum = fabs(cx) + fabs(cy); dif = fabs(cy) - fabs(cx);
-                dm_ = fmax(sum, kc_tiny);
+                // the divisor's guard against digital silence: sum + 1e-100 IS sum unless sum is 0 (a non-zero sum of
+                // products of window sums is far above 1e-84), and an add needs no canonicalised operand where fmax does
+                dm_ = sum + kc_tiny;
             } else {
-                asm("s_nop 1\n\t"                                   // (the select's two wait states; once per demodulate() call)
-                    "v_mov_b64_dpp %0, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-                    "v_mov_b64_dpp %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf"
-                    : "=&v"(ee), "=&v"(el) : "v"(seln));
+                ee = row_bcast<2>(sq, seln); el = row_bcast<3>(shv, seln);
             }
             const double den = el + ee + kc_eps;                    // ted = num/den (ref :275/:279)
 
@@ -943,8 +941,9 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 // own residual step - the same error profile as with two (scripts/microbench/rcp_accuracy.hip)
                 y = fma(fma(-tt, y, 1.0), y, y);
                 const double iden = y * dm, idm = y * den;
-                double ratio = dif * idm;                           // q = (|cy| - |cx|) / (|cy| + |cx|) in [-1, 1]
-                ratio = fma(fma(-dm, ratio, dif), idm, ratio);
+                // q = (|cy| - |cx|) / (|cy| + |cx|) in [-1, 1], good to 2^-48 without a residual step: 3.5e-15 rad on the
+                // angle, i.e. 3e-14 Hz x afc_alpha / 0.001 on fo - nothing rounds on it the way pos does on ted
+                const double ratio = dif * idm;
                 const double kd = rint(ratio * kc_64);              // nearest expansion point k/64, k = -64..64
                 const int k = (int)kd;
                 h = fma(kd, kc_m1_64, ratio);                       // |h| <= 1/128
