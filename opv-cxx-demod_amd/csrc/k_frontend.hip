@@ -340,8 +340,8 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     double kc_tiny = 1e-100;
     asm volatile("" : "+v"(kc_tiny));
     double kc_halfpi = 1.57079632679489661923, kc_32 = 32.0, kc_m1_32 = -1.0 / 32.0, kc_gain = st.afc_alpha * (kSymRate / kTwoPi);
-    [[maybe_unused]] double kc_64 = 64.0, kc_m1_64 = -1.0 / 64.0;
-    asm volatile("" : "+v"(kc_64), "+v"(kc_m1_64));
+    [[maybe_unused]] double kc_64 = 64.0, kc_m1_64 = -1.0 / 64.0, kc_magic = 6755399441055744.0 + 64.0;   // 1.5 * 2^52 + 64
+    asm volatile("" : "+v"(kc_64), "+v"(kc_m1_64), "+v"(kc_magic));
     asm volatile("" : "+v"(kc_tfmax), "+v"(kc_beta), "+v"(kc_alpha), "+v"(kc_fomax), "+v"(kc_eps));
     asm volatile("" : "+v"(kc_halfpi), "+v"(kc_32), "+v"(kc_m1_32), "+v"(kc_gain));
     const double kc_nfomax = __builtin_canonicalize(-kc_fomax), kc_ntfmax = __builtin_canonicalize(-kc_tfmax);
@@ -892,6 +892,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             // tone 1 iff e1 > e2 (ref :272 / :291; a tie gives +0: tone 2). sg = +1 for tone 1, -1 for tone 2.
             const bool dom1 = soft < 0.0;
             nsg = mkd((dhi(soft) & (int)0x80000000) | (dhi(nsg) & 0x7fffffff), dlo(nsg));
+            asm volatile("" : "+v"(nsg));                           // (updated in place: no copy of the low word)
             const double sg = -nsg;
             const double oth = mkd(__builtin_amdgcn_mov_dpp(dhi(en), 0x102, 0xF, 0xF, true), __builtin_amdgcn_mov_dpp(dlo(en), 0x102, 0xF, 0xF, true));
             __builtin_amdgcn_sched_barrier(0);
@@ -944,10 +945,12 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 // q = (|cy| - |cx|) / (|cy| + |cx|) in [-1, 1], good to 2^-48 without a residual step: 3.5e-15 rad on the
                 // angle, i.e. 3e-14 Hz x afc_alpha / 0.001 on fo - nothing rounds on it the way pos does on ted
                 const double ratio = dif * idm;
-                const double kd = rint(ratio * kc_64);              // nearest expansion point k/64, k = -64..64
-                const int k = (int)kd;
+                // nearest expansion point k/64, k = -64..64, by the 1.5 * 2^52 trick: the sum's low word IS the row index
+                // k + 64, and subtracting the constant gives k as a double - no v_rndne, no v_cvt
+                const double kt = fma(ratio, kc_64, kc_magic);
+                const double kd = kt - kc_magic;
                 h = fma(kd, kc_m1_64, ratio);                       // |h| <= 1/128
-                const unsigned char* rowb = reinterpret_cast<const unsigned char*>(atab) + 64 * 64 + k * 64;
+                const unsigned char* rowb = reinterpret_cast<const unsigned char*>(atab) + ((unsigned)dlo(kt) << 6);
                 const double2* trow = reinterpret_cast<const double2*>(rowb);
                 c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
                 ted = num * iden;
