@@ -293,7 +293,7 @@ def main():
                    "parallelism": f"streams sharded {S}/GPU, no data-path collective"},
         "frames_checked": f"rank0: {stats.get('frames_exact')}/{stats.get('frames_total')} decoded frames equal the "
                           f"transmitted bytes (rest = channel errors at {args.ebn0:g} dB); GPU==reference parity is tests/",
-        "roofline": {"bound": "hbm", "kernel": "k_msk_frontend", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_msk_frontend_rb", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "traffic_note": traffic_note,
                      "issue": issue,

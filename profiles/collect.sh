@@ -42,14 +42,15 @@ def val(i, kernel, counter):
             return float(re.search(r"per_dispatch=(\S+)", ln).group(1))
     return None
 S, F = 64, 1000
+K = "k_msk_frontend_rb"            # the front-end kernel the shim launches for this workload (one wave per stream, row-broadcast reduction)
 n_sym = S * 2168099.0                     # symbols one launch demodulates (86 724 000 samples per stream, ~40 per symbol)
-fetch, write = val(1, "k_msk_frontend", "FETCH_SIZE"), val(2, "k_msk_frontend", "WRITE_SIZE")
-ips = {k: round(val(3, "k_msk_frontend", c) / n_sym, 2) for k, c in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS"))}
-out = {"kernel": "k_msk_frontend", "workload": {"streams_per_gpu": S, "frames_per_stream": F, "ebn0": 16.0},
+fetch, write = val(1, K, "FETCH_SIZE"), val(2, K, "WRITE_SIZE")
+ips = {k: round(val(3, K, c) / n_sym, 2) for k, c in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS"))}
+out = {"kernel": K, "workload": {"streams_per_gpu": S, "frames_per_stream": F, "ebn0": 16.0},
        "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
        "hbm_read_bytes_per_launch": fetch * 1024 * 2, "hbm_write_bytes_per_launch": write * 1024,
        "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
-       "instr_per_symbol": ips, "wave_cycles_per_symbol": round(val(3, "k_msk_frontend", "SQ_WAVE_CYCLES") * 4 / n_sym, 1),
+       "instr_per_symbol": ips, "wave_cycles_per_symbol": round(val(3, K, "SQ_WAVE_CYCLES") * 4 / n_sym, 1),
        "correction": "gfx950: FETCH_SIZE counts wide (16 B/lane) coalesced reads at 1/2 -> x2 (MI355X_MICROARCH.md §HBM); WRITE_SIZE exact; units are KiB",
        "source": f"profiles/{TAG}_pmc_1.txt (FETCH_SIZE pass), profiles/{TAG}_pmc_2.txt (WRITE_SIZE pass), profiles/{TAG}_pmc_3.txt (SQ_INSTS_*, SQ_WAVE_CYCLES x 4), rocprofv3 --pmc, separate passes, command: python3 bench.py --no-extras --steps 1 --warmup 0"}
 json.dump(out, open(f"{O}/{TAG}_traffic.json", "w"), indent=1)
