@@ -4,7 +4,8 @@
 // (the only DPP controls 64-bit operations take: llvm-mc, "DP ALU dpp only supports row_newbcast").
 // With them a row of 16 lanes can form 16 differently weighted sums of its 16 values in 16 instructions - a
 // candidate replacement for the front-end's products + permlane / DPP-rotation reductions + v_readlane hand-outs.
-// Prints cycles per instruction (s_memtime) and checks the semantics on the way.
+// Prints cycles per pass (s_memtime; a pass of the empty loop costs 36, overlapping partly with the work) and checks the
+// semantics on the way. A plain dependent fp64 FMA costs a lone wave 4.6 cycles (lone_wave.hip, 64 per pass).
 // Build: hipcc -O3 --offload-arch=gfx950 -o dpp64 dpp64.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -124,6 +125,18 @@ __global__ void k_rows_allreduce(double* out, unsigned long long* cyc, int rep) 
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// the loop itself (counter, compare, branch), subtracted from every figure below
+__global__ void k_empty(double* out, unsigned long long* cyc, int rep) {
+    double x = out[threadIdx.x];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int r = 0; r < rep; ++r) asm volatile("" : "+v"(x));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    out[threadIdx.x] = x;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+static double g_loop = 0.0, g_plain = 0.0;   // cycles per pass of the empty loop / of 16 plain dependent FMACs
+static bool k_is_plain = false;
+
 template <typename K>
 static void run(const char* name, K k, int per_rep, int rep = 4000) {
     double* d; unsigned long long* c;
@@ -134,7 +147,10 @@ static void run(const char* name, K k, int per_rep, int rep = 4000) {
     k<<<1, 64>>>(d, c, rep);
     CK(hipDeviceSynchronize());
     unsigned long long cy; CK(hipMemcpy(&cy, c, 8, hipMemcpyDeviceToHost));
-    printf("%-28s %7.2f cycles per instruction (%d instructions per pass)\n", name, (double)cy / rep / per_rep, per_rep);
+    if (per_rep == 0) { g_loop = (double)cy / rep; printf("%-28s %7.2f cycles per pass\n", name, g_loop); }
+    else printf("%-28s %7.1f cycles per pass of %d instructions (+%.2f per instruction over the same number of plain dependent v_fmac_f64)\n",
+                name, (double)cy / rep, per_rep, g_plain > 0 ? ((double)cy / rep - g_plain * per_rep / 16.0) / per_rep : 0.0);
+    if (k_is_plain) g_plain = (double)cy / rep;
     CK(hipFree(d)); CK(hipFree(c));
 }
 
@@ -154,11 +170,12 @@ int main() {
     for (int l = 0; l < 64; ++l) if (h[128 + l] != h[(l / 16) * 16 + 5]) ++bc;
     printf("v_mov_b64_dpp row_newbcast with bound_ctrl:1: %s (%d lanes differ from the broadcast)\n", bc ? "NOT a broadcast" : "same as without", bc);
     printf("semantics: %s\n", bad ? "MISMATCH" : "ok (fmac: dst += src0[row lane n] * src1[own lane]; mov: dst = src0[row lane n])");
-    run("v_fmac_f64 plain, dependent", k_fmac_plain, 16);
+    run("empty loop", k_empty, 0);
+    k_is_plain = true; run("v_fmac_f64 plain, dependent", k_fmac_plain, 16); k_is_plain = false;
     run("v_fmac_f64_dpp, dependent", k_fmac_dpp_dep, 16);
     run("v_fmac_f64_dpp, 2 accum.", k_fmac_dpp_2acc, 16);
     run("v_mov_b64_dpp", k_mov_dpp, 16);
     run("add + s_nop 1 + fmac_dpp", k_fmac_dpp_fresh, 48);
-    run("rows all-reduce, per pass", k_rows_allreduce, 4);
+    run("4 x (rows all-reduce + ldexp)", k_rows_allreduce, 52);   // 2 x (2 movs, s_nop, 2 swaps, add) + v_ldexp each
     return bad;
 }
