@@ -19,7 +19,8 @@
 // MI355X mapping
 //   * Lane j (0..59) owns ONE interpolated sample  Lam_j = L(pos + j - 10). The three gates
 //     are the same 60 values under three shifts: early uses lanes 0..39, on-time 10..49, late
-//     20..59, so the 120 interpolations of the reference become 60, one per lane.
+//     20..59, so the 120 interpolations of the reference become 60, one per lane. (Row-broadcast body: 15 samples per
+//     row of 16 lanes, lane 16 r + n <-> sample 15 r + n; a row's last lane carries no weight.)
 //   * The LO is factored  lo_t[i] = E_t * T_t[i] * X[i],  E_t = exp(j ph_t) (a rotation that
 //     every use below is invariant to, so it is never formed and no phase is tracked),
 //     T_t[i] = exp(-/+ j 2pi i/160) a per-lane CONSTANT (13550*40 = Fs/4), and
@@ -31,12 +32,18 @@
 //     previous on-time correlation is advanced by the LO rotation of one symbol,
 //     P_t = S_t * (-/+ j) * X[40]  (T_t[40] = -/+ j exactly), so that
 //     arg(c(k) conj(c(k-1))) = arg(S(k) conj(P(k-1))).
-//   * Sums over the wave: v_permlane32_swap / v_permlane16_swap (reduce-scatter, 2 steps) + DPP
-//     row rotations, result handed to every lane by v_readlane (no LDS scratch). The on-time gate
-//     goes first (4 values); it decides the soft value and the dominant tone, and only THEN do the
-//     lanes form their early/late products - for the dominant tone alone, so the second reduction
-//     also carries 4 values instead of 8. The scalar loop filters run redundantly on all lanes
-//     (wave-uniform, no divergence).
+//   * Sums over the wave, current body (`symbol_r`, kernels k_msk_frontend_rb / _rb_wg4): the DP-ALU DPP form
+//     v_fmac_f64_dpp acc, src0 row_newbcast:n, src1 lets a row of 16 lanes form 16 differently weighted sums of its
+//     samples; with 15 samples per row, 2 x 15 FMACs give ALL window sums of the symbol (on-time / early / late
+//     correlations of both tones + the on-time sums P1..P4) as row partials in lane t = lane & 15, one all-reduce over
+//     the four rows completes them, v_mov_b64_dpp row_newbcast hands out what the loop filters need, the energies and
+//     the dominant-tone select are lane-parallel. 157 VALU instructions per symbol.
+//     Round-1 body (`symbol`, kernels k_msk_frontend / _wg4 / _dual, mapping -1 / -2): products per lane, then
+//     v_permlane32_swap / v_permlane16_swap (reduce-scatter, 2 steps) + DPP row rotations, result handed to every lane
+//     by v_readlane (no LDS scratch). The on-time gate goes first (4 values); it decides the soft value and the
+//     dominant tone, and only THEN do the lanes form their early/late products - for the dominant tone alone, so the
+//     second reduction also carries 4 values instead of 8. 197 VALU instructions per symbol.
+//     Either way the scalar loop filters run redundantly on all lanes (wave-uniform, no divergence).
 //   * A LONE wave on a SIMD issues one instruction of ANY kind (VALU, SALU, LDS, s_nop, branch)
 //     every ~4.7 cycles and gains nothing from independent chains (scripts/microbench): the
 //     symbol rate is set by the instruction COUNT of the loop body. Hence: no per-symbol
