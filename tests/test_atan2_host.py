@@ -48,15 +48,48 @@ def test_atan2_table_matches_libm(tmp_path):
                                  # the AFC integrates pd, so the ABSOLUTE error is what matters
 
 
+SRC_Q = SRC.replace("opv_atan2(", "opv_atan2_q(")
+
+
+def test_atan2_q_table_matches_libm(tmp_path):
+    """opv_atan2_q (the row-broadcast front-end's angle: pi/4 + atan((|y| - |x|) / (|y| + |x|)), 129 rows, degree 7, no
+    octant fix-up): ABSOLUTE accuracy like opv_atan2; the relative accuracy of tiny angles is that of an angle near
+    pi/4 by construction (the AFC integrates the angle), so only the absolute error is asserted. Axis arguments exact."""
+    c = tmp_path / "t.cpp"
+    c.write_text(SRC_Q)
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", str(ROOT / "opv-cxx-demod_amd" / "csrc"), str(c), "-o",
+                    str(exe), "-lm"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert float(out[0]) < 5e-16
+    c.write_text(r"""
+#include <math.h>
+#include <stdio.h>
+#include "opv_atan2.h"
+int main() {
+    const double pi = 3.14159265358979323846;
+    int ok = opv_atan2_q(0.0, 1.0) == 0.0 && opv_atan2_q(0.0, -1.0) == pi && opv_atan2_q(1.0, 0.0) == pi / 2 &&
+             opv_atan2_q(-1.0, 0.0) == -pi / 2 && opv_atan2_q(3.0, 3.0) == pi / 4 && opv_atan2_q(-2.0, -2.0) == -3 * pi / 4;
+    printf("%d\n", ok);
+    return 0;
+}
+""")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", str(ROOT / "opv-cxx-demod_amd" / "csrc"), str(c), "-o",
+                    str(exe), "-lm"], check=True)
+    assert subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip() == "1"
+
+
 def test_table_is_reproducible(tmp_path):
-    """The committed table equals what tools/gen_atan_table.py generates (mpmath, 60 digits)."""
+    """The committed tables equal what tools/gen_atan_table.py generates (mpmath, 60 digits)."""
     import shutil
     pkg = ROOT / "opv-cxx-demod_amd"
-    inc = pkg / "csrc" / "opv_atan_table.inc"
-    before = inc.read_text()
-    shutil.copy(inc, tmp_path / "keep.inc")
+    incs = [pkg / "csrc" / "opv_atan_table.inc", pkg / "csrc" / "opv_atan_table_q.inc"]
+    before = [inc.read_text() for inc in incs]
+    for k, inc in enumerate(incs):
+        shutil.copy(inc, tmp_path / f"keep{k}.inc")
     try:
         subprocess.run(["python3", str(pkg / "tools" / "gen_atan_table.py")], check=True, capture_output=True)
-        assert inc.read_text() == before
+        assert [inc.read_text() for inc in incs] == before
     finally:
-        shutil.copy(tmp_path / "keep.inc", inc)
+        for k, inc in enumerate(incs):
+            shutil.copy(tmp_path / f"keep{k}.inc", inc)
