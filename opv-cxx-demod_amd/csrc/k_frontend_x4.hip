@@ -35,6 +35,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include <type_traits>
+
 #include "opv_device.h"
 
 namespace {
@@ -249,6 +251,139 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
         if (held_valid) *(gdouble*)(soft_base + held_off) = held;
         held_valid = false;
     };
+    // One symbol of every row that executes this (exec = the rows inside a demodulate() call whose next symbol exists).
+    // Generic: with the tests the first symbols of a call need (early gate before the chunk, no AFC on the first symbol,
+    // an out-of-range -o still in force). Fast: the same statements without them - bit-identical where both apply
+    // (no contraction, no re-association) - for the batches below. `slot`: which of a row's four soft-log lanes keeps
+    // this symbol's value until the next flush.
+    auto symbol_body = [&](auto generic_tag, uint32_t slot) {
+        constexpr bool kGeneric = decltype(generic_tag)::value;
+        // ---- taps (ref :122-128, :232-238) --------------------------------------------------
+        const double pf = pos + kf0;
+        const double fl = floor(pf);
+        const double f = pf - fl;
+        const int i0 = (int)fl;
+        const uint32_t byte0 = (((uint32_t)(i0 + (int)origin)) << 2) & (kRingBytes - 1u);
+        int w0[4], w1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int* tap = reinterpret_cast<const int*>(ring + byte0 + 64u * (uint32_t)q);
+            w0[q] = tap[0];
+            w1[q] = tap[1];
+        }
+        if (kGeneric && first && pf < 0.0) {                           // early gate before the chunk: s[0] (ref :237)
+            const int s0 = *reinterpret_cast<const int*>(ring + ((origin << 2) & (kRingBytes - 1u)));
+            w0[0] = s0;
+            w1[0] = s0;
+        }
+        // ---- LO: X[m] for m = t - 10 + 16 q ---------------------------------------------------
+        double xs[4], xc[4], s16, c16;
+        expj_small(kfs0 * fo, xs[0], xc[0]);
+        expj_small((16.0 * kDeltaPerHz) * fo, s16, c16);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            xc[q] = fma(xc[q - 1], c16, -(xs[q - 1] * s16));
+            xs[q] = fma(xc[q - 1], s16, xs[q - 1] * c16);
+        }
+        // X[40] = exp(j 40 d): uniform per row, needed by the NEXT symbol's phase detector
+        double x40s, x40c;
+        expj_small((40.0 * kDeltaPerHz) * fo, x40s, x40c);
+        if (kGeneric && fabs(fo) > 2000.0) {
+            // -o takes any value (ref :1004-1005) and the AFC clamp (:303) first acts at the END of the
+            // call's second symbol: outside the polynomial's range those symbols take the full-range routine
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sincos((kfs0 + (16.0 * q) * kDeltaPerHz) * fo, &xs[q], &xc[q]);
+            sincos((40.0 * kDeltaPerHz) * fo, &x40s, &x40c);
+        }
+
+        double o1 = 0, o2 = 0, o3 = 0, o4 = 0;             // on-time P1..P4 partials
+        double eA = 0, eB = 0, eC = 0, eD = 0, lA = 0, lB = 0, lC = 0, lD = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s0r = (int)(short)(w0[q] & 0xFFFF), s0i = w0[q] >> 16;    // ref :1023
+            const int d_r = (int)(short)(w1[q] & 0xFFFF) - s0r, d_i = (w1[q] >> 16) - s0i;
+            const double lr = fma(f, (double)d_r, (double)s0r);
+            const double li = fma(f, (double)d_i, (double)s0i);
+            const double zr = fma(lr, xc[q], li * xs[q]);   // Z = Lam conj(X)
+            const double zi = fma(li, xc[q], -(lr * xs[q]));
+            o1 = fma(zr, aO[q], o1); o2 = fma(zi, bO[q], o2); o3 = fma(zi, aO[q], o3); o4 = fma(zr, bO[q], o4);
+            if (q < 3) { eA = fma(zr, aE[q], eA); eB = fma(zi, aE[q], eB); eC = fma(zi, bE[q], eC); eD = fma(zr, bE[q], eD); }
+            if (q > 0) { lA = fma(zr, aL[q], lA); lB = fma(zi, aL[q], lB); lC = fma(zi, bL[q], lC); lD = fma(zr, bL[q], lD); }
+        }
+        // ---- on-time gate: soft value, dominant tone (ref :264-272) --------------------------
+        const double P1o = row_sum(o1), P2o = row_sum(o2), P3o = row_sum(o3), P4o = row_sum(o4);
+        const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;
+        const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;
+        const double en1 = fma(s1r_, s1r_, s1i_ * s1i_);
+        const double en2 = fma(s2r_, s2r_, s2i_ * s2i_);
+        const double soft = en2 - en1;                      // ref :268
+        const double nsg = mkd((dhi(soft) & (int)0x80000000) | 0x3ff00000, 0);  // -1 iff tone 1 dominates
+        const double sg = -nsg;
+        // ---- early / late gates of the dominant tone (ref :271-280) ---------------------------
+        const double Ere = row_sum(fma(sg, eC, eA)), Eim = row_sum(fma(-sg, eD, eB));
+        const double Lre = row_sum(fma(sg, lC, lA)), Lim = row_sum(fma(-sg, lD, lB));
+        const double ee = fma(Ere, Ere, Eim * Eim), el = fma(Lre, Lre, Lim * Lim);
+        const double num = el - ee, den = el + ee + 1e-10;
+        // ---- phase detector operands: dom * conj(prev) (ref :289-299, see k_frontend.hip) -----
+        const double dr = fma(sg, P2o, P1o), di = fma(-sg, P4o, P3o);
+        const double prs = fma(sg, pv.a, pv.b), pis = fma(sg, pv.c, -pv.d);
+        const double ar = fma(dr, prs, di * pis), ai = fma(di, prs, -(dr * pis));
+        const double cy = fma(ar, pv.x40c, ai * pv.x40s);   // Im z
+        const double cx = fma(ar, pv.x40s, -(ai * pv.x40c)); // Re z
+        const double ax = fabs(cx), ay = fabs(cy);
+        const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+        // ---- the two divides on one reciprocal ------------------------------------------------
+        const double dm = fmax(mx, 1e-100);
+        const double tt = den * dm;
+        double y = __builtin_amdgcn_rcp(tt);
+        y = fma(fma(-tt, y, 1.0), y, y);
+        y = fma(fma(-tt, y, 1.0), y, y);
+        const double iden = y * dm, idm = y * den;
+        double ratio = mn * idm;
+        ratio = fma(fma(-dm, ratio, mn), idm, ratio);
+        double ted = num * iden;
+        ted = fma(fma(-den, ted, num), iden, ted);
+        // ---- timing loop (ref :283-286, :313) ------------------------------------------------
+        tf = clampd(fma(0.00001, ted, tf), -0.1, 0.1);
+        const double adj = fma(0.005, ted, tf);   // |adj| <= 0.105: the reference's clamp to +/-2 (:286) cannot act, see k_frontend.hip
+        const double pos_next = pos + (40.0 + adj);
+        if ((uint32_t)t == slot) { held = soft; held_off = soft_off; held_valid = true; }
+        // ---- AFC (ref :289-306): not on the first symbol of a call -------------------------------
+        if (!kGeneric || !first) {
+            const double kd = rint(ratio * 32.0);
+            const int k = (int)kd;
+            const double h = fma(kd, -1.0 / 32.0, ratio);
+            const double* trow = atab + k * (int)kTabRow;
+            double pd = fma(trow[8], h, trow[7]);
+            pd = fma(pd, h, trow[6]);
+            pd = fma(pd, h, trow[5]);
+            pd = fma(pd, h, trow[4]);
+            pd = fma(pd, h, trow[3]);
+            pd = fma(pd, h, trow[2]);
+            pd = fma(pd, h, trow[1]);
+            pd = fma(pd, h, trow[0]);
+            pd = (ay > ax) ? 1.57079632679489661923 - pd : pd;
+            const double sx = mkd((dhi(cx) & (int)0x80000000) | 0x3ff00000, 0);
+            pd = fma(sx, pd, fma(-sx, 1.57079632679489661923, 1.57079632679489661923));
+            pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));
+            if (mx == 0.0) {                                 // digital silence on either side
+                const double2 sp = silence_pd_x4(dr, di, pv.a, pv.b, pv.c, pv.d, pv.x40c, pv.x40s, soft < 0.0, fo_sum,
+                                                 (uint32_t)n_soft + (((soft_off - soft_off0) & soft_bmask) >> 3),
+                                                 P1o, P2o, P3o, P4o);
+                pd = sp.x;
+                edge_ties += (uint32_t)sp.y;
+            }
+            const double fo_used = fo;
+            fo = clampd(fma(kgain, pd, fo), -2000.0, 2000.0);
+            fo_sum += fo_used;
+        } else {
+            fo_sum += fo;
+        }
+        soft_off = (soft_off + 8u) & soft_bmask;
+        pv.a = P1o; pv.b = P2o; pv.c = P3o; pv.d = P4o; pv.x40c = x40c; pv.x40s = x40s;
+        pos = pos_next;
+        first = false;
+    };
     refill(!done, origin + (uint32_t)(int)mu, 16);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();                     // atan table visible (single wave: LDS ordering only)
@@ -282,6 +417,36 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
         }
         if (__ballot(in_call) == 0ull) break;
 
+        // ---- batches: as many symbols as EVERY row inside a call can take without its end-of-call test, its first-symbol
+        // rules or an out-of-range -o (pos advances by at most 42 samples per symbol), in groups of four (the soft-log
+        // lanes and the refill points keep their rhythm); the per-symbol bookkeeping of the loop below - what makes up a
+        // third of its instructions - is then paid once per batch. Rows outside a call are finished streams here (a row
+        // that could start a call has just done so and asks for 0): they sit the batch out under the exec mask.
+        if ((iter & 3u) == 0u) {
+            int krow = 0x7fffffff;
+            if (in_call) {
+                krow = 0;
+                const double room = Nd - 51.0 - pos;
+                if (!first && !(fabs(fo) > 2000.0) && room > 0.0) krow = (int)(room * (1.0 / 42.0));
+            }
+            int kmin = __builtin_amdgcn_readlane(krow, 0);
+            { const int k1 = __builtin_amdgcn_readlane(krow, 16); kmin = k1 < kmin ? k1 : kmin; }
+            { const int k2 = __builtin_amdgcn_readlane(krow, 32); kmin = k2 < kmin ? k2 : kmin; }
+            { const int k3 = __builtin_amdgcn_readlane(krow, 48); kmin = k3 < kmin ? k3 : kmin; }
+            for (uint32_t quads = (uint32_t)kmin >> 2; quads != 0u; --quads) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): blocks and stores issued 4 symbols ago
+                flush_soft();
+                refill(in_call, origin + (uint32_t)(int)pos, 4);
+                if (in_call) {
+                    symbol_body(std::false_type{}, 0u);
+                    symbol_body(std::false_type{}, 1u);
+                    symbol_body(std::false_type{}, 2u);
+                    symbol_body(std::false_type{}, 3u);
+                }
+                iter += 4u;
+            }
+        }
+
         if ((iter & 3u) == 0u) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): blocks and stores issued 4 symbols ago
             flush_soft();
@@ -290,131 +455,7 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
 
         if (in_call) {
             if (pos + 40.0 + 10.0 < Nd) {                          // ref :221
-                // ---- taps (ref :122-128, :232-238) --------------------------------------------------
-                const double pf = pos + kf0;
-                const double fl = floor(pf);
-                const double f = pf - fl;
-                const int i0 = (int)fl;
-                const uint32_t byte0 = (((uint32_t)(i0 + (int)origin)) << 2) & (kRingBytes - 1u);
-                int w0[4], w1[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int* tap = reinterpret_cast<const int*>(ring + byte0 + 64u * (uint32_t)q);
-                    w0[q] = tap[0];
-                    w1[q] = tap[1];
-                }
-                if (first && pf < 0.0) {                           // early gate before the chunk: s[0] (ref :237)
-                    const int s0 = *reinterpret_cast<const int*>(ring + ((origin << 2) & (kRingBytes - 1u)));
-                    w0[0] = s0;
-                    w1[0] = s0;
-                }
-                // ---- LO: X[m] for m = t - 10 + 16 q ---------------------------------------------------
-                double xs[4], xc[4], s16, c16;
-                expj_small(kfs0 * fo, xs[0], xc[0]);
-                expj_small((16.0 * kDeltaPerHz) * fo, s16, c16);
-#pragma unroll
-                for (int q = 1; q < 4; ++q) {
-                    xc[q] = fma(xc[q - 1], c16, -(xs[q - 1] * s16));
-                    xs[q] = fma(xc[q - 1], s16, xs[q - 1] * c16);
-                }
-                // X[40] = exp(j 40 d): uniform per row, needed by the NEXT symbol's phase detector
-                double x40s, x40c;
-                expj_small((40.0 * kDeltaPerHz) * fo, x40s, x40c);
-                if (fabs(fo) > 2000.0) {
-                    // -o takes any value (ref :1004-1005) and the AFC clamp (:303) first acts at the END of the
-                    // call's second symbol: outside the polynomial's range those symbols take the full-range routine
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) sincos((kfs0 + (16.0 * q) * kDeltaPerHz) * fo, &xs[q], &xc[q]);
-                    sincos((40.0 * kDeltaPerHz) * fo, &x40s, &x40c);
-                }
-
-                double o1 = 0, o2 = 0, o3 = 0, o4 = 0;             // on-time P1..P4 partials
-                double eA = 0, eB = 0, eC = 0, eD = 0, lA = 0, lB = 0, lC = 0, lD = 0;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int s0r = (int)(short)(w0[q] & 0xFFFF), s0i = w0[q] >> 16;    // ref :1023
-                    const int d_r = (int)(short)(w1[q] & 0xFFFF) - s0r, d_i = (w1[q] >> 16) - s0i;
-                    const double lr = fma(f, (double)d_r, (double)s0r);
-                    const double li = fma(f, (double)d_i, (double)s0i);
-                    const double zr = fma(lr, xc[q], li * xs[q]);   // Z = Lam conj(X)
-                    const double zi = fma(li, xc[q], -(lr * xs[q]));
-                    o1 = fma(zr, aO[q], o1); o2 = fma(zi, bO[q], o2); o3 = fma(zi, aO[q], o3); o4 = fma(zr, bO[q], o4);
-                    if (q < 3) { eA = fma(zr, aE[q], eA); eB = fma(zi, aE[q], eB); eC = fma(zi, bE[q], eC); eD = fma(zr, bE[q], eD); }
-                    if (q > 0) { lA = fma(zr, aL[q], lA); lB = fma(zi, aL[q], lB); lC = fma(zi, bL[q], lC); lD = fma(zr, bL[q], lD); }
-                }
-                // ---- on-time gate: soft value, dominant tone (ref :264-272) --------------------------
-                const double P1o = row_sum(o1), P2o = row_sum(o2), P3o = row_sum(o3), P4o = row_sum(o4);
-                const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;
-                const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;
-                const double en1 = fma(s1r_, s1r_, s1i_ * s1i_);
-                const double en2 = fma(s2r_, s2r_, s2i_ * s2i_);
-                const double soft = en2 - en1;                      // ref :268
-                const double nsg = mkd((dhi(soft) & (int)0x80000000) | 0x3ff00000, 0);  // -1 iff tone 1 dominates
-                const double sg = -nsg;
-                // ---- early / late gates of the dominant tone (ref :271-280) ---------------------------
-                const double Ere = row_sum(fma(sg, eC, eA)), Eim = row_sum(fma(-sg, eD, eB));
-                const double Lre = row_sum(fma(sg, lC, lA)), Lim = row_sum(fma(-sg, lD, lB));
-                const double ee = fma(Ere, Ere, Eim * Eim), el = fma(Lre, Lre, Lim * Lim);
-                const double num = el - ee, den = el + ee + 1e-10;
-                // ---- phase detector operands: dom * conj(prev) (ref :289-299, see k_frontend.hip) -----
-                const double dr = fma(sg, P2o, P1o), di = fma(-sg, P4o, P3o);
-                const double prs = fma(sg, pv.a, pv.b), pis = fma(sg, pv.c, -pv.d);
-                const double ar = fma(dr, prs, di * pis), ai = fma(di, prs, -(dr * pis));
-                const double cy = fma(ar, pv.x40c, ai * pv.x40s);   // Im z
-                const double cx = fma(ar, pv.x40s, -(ai * pv.x40c)); // Re z
-                const double ax = fabs(cx), ay = fabs(cy);
-                const double mx = fmax(ax, ay), mn = fmin(ax, ay);
-                // ---- the two divides on one reciprocal ------------------------------------------------
-                const double dm = fmax(mx, 1e-100);
-                const double tt = den * dm;
-                double y = __builtin_amdgcn_rcp(tt);
-                y = fma(fma(-tt, y, 1.0), y, y);
-                y = fma(fma(-tt, y, 1.0), y, y);
-                const double iden = y * dm, idm = y * den;
-                double ratio = mn * idm;
-                ratio = fma(fma(-dm, ratio, mn), idm, ratio);
-                double ted = num * iden;
-                ted = fma(fma(-den, ted, num), iden, ted);
-                // ---- timing loop (ref :283-286, :313) ------------------------------------------------
-                tf = clampd(fma(0.00001, ted, tf), -0.1, 0.1);
-                const double adj = fma(0.005, ted, tf);   // |adj| <= 0.105: the reference's clamp to +/-2 (:286) cannot act, see k_frontend.hip
-                const double pos_next = pos + (40.0 + adj);
-                if ((uint32_t)t == (iter & 3u)) { held = soft; held_off = soft_off; held_valid = true; }
-                // ---- AFC (ref :289-306): not on the first symbol of a call -------------------------------
-                if (!first) {
-                    const double kd = rint(ratio * 32.0);
-                    const int k = (int)kd;
-                    const double h = fma(kd, -1.0 / 32.0, ratio);
-                    const double* trow = atab + k * (int)kTabRow;
-                    double pd = fma(trow[8], h, trow[7]);
-                    pd = fma(pd, h, trow[6]);
-                    pd = fma(pd, h, trow[5]);
-                    pd = fma(pd, h, trow[4]);
-                    pd = fma(pd, h, trow[3]);
-                    pd = fma(pd, h, trow[2]);
-                    pd = fma(pd, h, trow[1]);
-                    pd = fma(pd, h, trow[0]);
-                    pd = (ay > ax) ? 1.57079632679489661923 - pd : pd;
-                    const double sx = mkd((dhi(cx) & (int)0x80000000) | 0x3ff00000, 0);
-                    pd = fma(sx, pd, fma(-sx, 1.57079632679489661923, 1.57079632679489661923));
-                    pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));
-                    if (mx == 0.0) {                                 // digital silence on either side
-                        const double2 sp = silence_pd_x4(dr, di, pv.a, pv.b, pv.c, pv.d, pv.x40c, pv.x40s, soft < 0.0, fo_sum,
-                                                         (uint32_t)n_soft + (((soft_off - soft_off0) & soft_bmask) >> 3),
-                                                         P1o, P2o, P3o, P4o);
-                        pd = sp.x;
-                        edge_ties += (uint32_t)sp.y;
-                    }
-                    const double fo_used = fo;
-                    fo = clampd(fma(kgain, pd, fo), -2000.0, 2000.0);
-                    fo_sum += fo_used;
-                } else {
-                    fo_sum += fo;
-                }
-                soft_off = (soft_off + 8u) & soft_bmask;
-                pv.a = P1o; pv.b = P2o; pv.c = P3o; pv.d = P4o; pv.x40c = x40c; pv.x40s = x40s;
-                pos = pos_next;
-                first = false;
+                symbol_body(std::true_type{}, iter & 3u);
             } else {
                 // ---- end of this demodulate() call (ref :318-328, :1067-1076) ---------------------
                 const uint32_t nsym_call = ((soft_off - soft_off0) & soft_bmask) >> 3;
