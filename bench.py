@@ -342,7 +342,7 @@ def main():
             m.enable_timing(True)
             ent = {}
             for spw in (1, 4):                          # streams per wavefront (opv_set_frontend)
-                if spw == 4 and ns < 4096:         # the four-per-wave mapping pays from 4096 streams on
+                if spw == 4 and ns < 4096:         # (the four-per-wave mapping is the automatic choice from 2049 streams on)
                     continue
                 m.set_frontend(spw)
                 for rep in range(2):

@@ -151,7 +151,7 @@ int opv_sync(opv_ctx* ctx);
 /* Stream-to-wavefront mapping of the front-end kernel (no counterpart in the reference, which is one thread
  * per process): 1 = one wavefront per stream (lowest per-symbol latency; right while the GPU has idle SIMDs),
  * 4 = four streams per wavefront (fewest issued instructions per symbol; right when every SIMD has work),
- * 0 = automatic (4 from 4096 streams per context; measured cross-over on MI355X).
+ * 0 = automatic (4 from 2049 streams per context; measured cross-over on MI355X).
  * Kept for comparison, never automatic: -1 = one wavefront per stream with the product + permlane-swap reductions
  * (the default until the row-broadcast reduction replaced it: 1041 against 880 cycles per symbol), -2 = TWO wavefronts
  * per stream, one per feedback loop (exact, 6 % slower than -1). Results do not depend on the mapping beyond the

@@ -2,20 +2,22 @@
 // (16 lanes), four interpolated samples per lane. Same arithmetic contract as k_frontend.hip
 // (reference src/opv-demod.cpp:206-329 + the chunker :1012-1113 / :1132-1173); selected by the shim
 // when a context carries enough streams to fill the chip without the one-wave-per-stream mapping
-// (opv_capi.hip: opv_set_frontend / automatic from 4096 streams).
+// (opv_capi.hip: opv_set_frontend / automatic from 2049 streams).
 //
 // Why: a symbol's loop filters, divides and atan2 are scalar work per STREAM. With one stream per
-// wave they are executed on 64 lanes for one result (about 100 of that kernel's 213 instructions per
-// symbol, plus 58 for two 64-lane reductions). Here a wave instruction advances four streams: the
-// scalar tail is shared by four, the reductions stay inside a DPP row (4 rotations, no cross-row
-// swaps, no v_readlane), and the per-sample work grows only from one to four taps per lane.
-// Measured (rocprofv3 PMC, MI355X): 448 VALU + 87 SALU + 12 LDS/VMEM per wave and symbol = 137 issued
-// instructions per symbol and stream instead of 210. Because a wave now carries four streams, the chip
-// fills four times later: launched four waves per workgroup (one per SIMD of a CU by construction, see
-// msk_frontend_x4_body) the mapping overtakes one-wave-per-stream at 4096 streams per GPU (front-end alone 118 vs
-// 110 GS/s; 130 vs 111 at 6144, 172 vs 111 at 8192; one wave per stream is bound by its SIMD's fp64 pipe at 101-111
-// GS/s from 2048 streams on); below that the one-wave kernel, with its shorter per-symbol latency, is the default
-// (DESIGN.md §3.1).
+// wave they are executed on 64 lanes for one result (about 65 of that kernel's 166 instructions per
+// symbol). Here a wave instruction advances four streams: the scalar tail is shared by four, the
+// reductions stay inside a DPP row (4 rotations, no cross-row swaps), and the per-sample work grows only
+// from one to four taps per lane. Rows reach their chunk ends, first symbols and refill points at different
+// symbols, so the loop carries per-row call state under exec masks; symbols run in BATCHES that provably need none
+// of it for any row (round 2: the same statements compiled without the tests), which took the per-wave-symbol count
+// (rocprofv3 PMC, MI355X, 4096 streams) from 448 VALU + 87 SALU + 12 LDS/VMEM to 372 + 57 + 9 = 110 issued
+// instructions per symbol and stream (one wave per stream: 166). Because a wave carries four streams the chip
+// fills four times later, and a launch lasts as long as one wave needs for its four streams: 68.7 ms for 30 frames
+// whether the context has 1025 or 4096 streams (four waves per workgroup = one per SIMD of a CU by construction, see
+// msk_frontend_x4_body), 99.7 ms for 8192 (two waves per SIMD): front-end alone 156 GS/s at 4096 streams, 214 at 8192.
+// The one-wave kernel runs 1024 streams at a time in 23.9 ms per 30 frames: faster up to 2048 streams, slower from
+// 2049 on, which is where the shim switches.
 //
 // Mapping (row r = lane / 16 serves stream 4*blockIdx.x + r, t = lane % 16):
 //   * lane t owns the interpolated samples Lam_j = L(pos + j - 10), j = t + 16 q, q = 0..3 (j < 60); the

@@ -55,7 +55,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 // double up on SIMDs (k_frontend.hip: msk_frontend_body)
 constexpr int kFrontendWg4MinStreams = 512;
 constexpr int kFrontendX4Wg4MaxStreams = 8192;   // 2048 waves = two 80 KB workgroups per CU; beyond that single-wave workgroups (20 KB)
-constexpr int kFrontendX4MinStreams = 4096;      // measured cross-over on MI355X: front-end alone 118 vs 110 GS/s at 4096 streams, 130 vs 111 at 6144
+constexpr int kFrontendX4MinStreams = 2049;      // measured on MI355X: one wave per stream runs 1024 streams at a time (47.8 ms per 2048 x 30 frames, 71 ms from 2049 on), four per wave 4096 (68.7 ms)
 
 struct StreamIn {  // host -> device per-round update
     const int16_t* iq;
@@ -453,9 +453,9 @@ extern "C" int opv_process(opv_ctx* c) {
     if (tm) HIPCHK(hipEventRecord(c->ev[0], c->stream));
     k_offset_search<<<S, 256, 0, c->stream>>>(c->d_streams, g, c->d_offs_wtab);
     if (tm) { HIPCHK(hipEventRecord(c->ev[1], c->stream)); HIPCHK(hipEventRecord(c->ev[2], c->stream)); }
-    // one wave per stream has the shortest per-symbol latency (what counts while SIMDs are idle, and up to
-    // two waves per SIMD); four streams per wave issue 137 instead of 213 instructions per symbol and
-    // stream, which only pays once there are more streams than the chip has wave slots for
+    // one wave per stream has the shortest per-symbol latency (what counts while SIMDs are idle); four streams per
+    // wave issue fewer instructions per symbol and stream, which pays once there are more streams than the one-wave
+    // kernel's two rounds of 1024 hold
     const bool x4 = c->frontend == 4 || (c->frontend == 0 && S >= kFrontendX4MinStreams);
     if (c->cfg.coherent && !c->cfg.streaming) {           // -c, batch only (ref :1144-1161)
         const double wn = c->cfg.pll_bw_hz * 2.0 * M_PI, zeta = 0.707, fsym = 2168000.0 / 40.0;   // set_pll_bandwidth (ref :551-558)
