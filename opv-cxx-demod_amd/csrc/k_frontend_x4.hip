@@ -28,8 +28,8 @@
 //   * every stream-level quantity (pos, fo, tf, previous sums, chunk bookkeeping) lives in VGPRs,
 //     replicated over the 16 lanes of its row; rows run their own chunk schedule under exec masks;
 //   * int16 IQ: a 1024-sample ring per row in LDS (+ 64-sample guard mirroring its head), refilled in
-//     64-sample blocks (one direct-to-LDS 16 B/lane load per row and block), requested 320+ samples
-//     before their first use and awaited with one s_waitcnt vmcnt(0) every fourth symbol.
+//     256-sample blocks (one direct-to-LDS 16 B/lane load of the WHOLE wave per row and block), requested
+//     one refill point (four symbols) before their first use and awaited with one s_waitcnt vmcnt(0) there.
 //
 // Differences from the reference are of the same kind and size as k_frontend.hip's (shared
 // interpolation fraction, factored LO, FMA, table atan2): soft symbols agree to ~1e-14 of their mean,
@@ -53,8 +53,13 @@ constexpr uint32_t kRingSamples = 1024;
 constexpr uint32_t kRingBytes = kRingSamples * 4;   // 4096
 constexpr uint32_t kGuardBytes = 256;               // mirror of the ring's first 64 samples
 constexpr uint32_t kRowBytes = kRingBytes + kGuardBytes;
-constexpr uint32_t kBlock = 64;                     // samples per refill block (16 lanes x 16 B)
-constexpr uint32_t kAheadMin = 544;                 // keep hi >= floor(pos) + this (56 reach + 4 symbols x 42 + 320)
+constexpr uint32_t kBlock = 256;                    // samples per refill block (64 lanes x 16 B: the WHOLE wave loads for one row)
+// Refill rule, applied every fourth symbol after the previous blocks have landed (g = floor(pos) of the row, hi = end of
+// what its ring holds): a symbol reads samples g - 11 .. g + 55 and g grows by at most 42 per symbol, so the four symbols
+// up to the next refill point need hi >= g + 182 NOW (invariant) and the ones after it hi >= g + 350 THEN. A block is
+// requested while hi < g + 648: it lands by the next refill point, where hi + 256 >= (g + 168) + 182 again, and it
+// overwrites samples below hi - 768 <= g - 120, which nothing reads any more. At most one block per row and refill point.
+constexpr uint32_t kAheadMin = 648;
 constexpr uint32_t kTabOff = 4 * kRowBytes;         // 17408
 constexpr uint32_t kTabRow = 10;
 // LDS per workgroup: WPB x kTabOff + the atan table = 20 048 B for one wave (eight workgroups per CU), 72 272 B for four (two)
@@ -200,9 +205,10 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
     double Nd = 0.0, pos = 0.0;
 
     // ---- ring refill ------------------------------------------------------------------------------
-    // hi: the row's ring holds absolute samples [hi - 1024, hi) (as far as the capture reaches); blocks
-    // of 64 samples, 256 B aligned in the capture. One direct-to-LDS load per row and block: lane l of
-    // the wave writes LDS byte m0 + 16 l, so the row's destination is passed as m0 = dst - 256 row.
+    // hi: the row's ring holds absolute samples [hi - 1024, hi) (as far as the capture reaches); blocks of 256 samples,
+    // 1 KB aligned in the capture, moved by ONE direct-to-LDS load of the whole wave (lane l writes LDS byte m0 + 16 l):
+    // all 64 lanes load for one row at a time, from that row's capture (its pointer and cursor broadcast by v_readlane).
+    // The ring head is mirrored into the guard by the row's own 16 lanes (64 samples).
     auto glds16 = [&](const gbyte* gsrc, uint32_t m0v) {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -225,6 +231,23 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
                     *reinterpret_cast<const __attribute__((address_space(1))) int*>(iq_bytes + off + 4u * j);
         }
     };
+    auto issue_wide = [&](int r, uint32_t hi_r) {   // all 64 lanes; r is a constant after unrolling
+        const uint32_t nb_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)n_bytes, 16 * r);
+        const uint32_t nb_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(n_bytes >> 32), 16 * r);
+        const uint64_t nb = ((uint64_t)nb_hi << 32) | nb_lo;
+        const uint64_t pb = (uint64_t)(uintptr_t)iq_bytes;
+        const uint32_t p_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pb, 16 * r);
+        const uint32_t p_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pb >> 32), 16 * r);
+        const gbyte* src = (const gbyte*)(uintptr_t)(((uint64_t)p_hi << 32) | p_lo);
+        const uint32_t dst = (hi_r * 4u) & (kRingBytes - 1u);
+        const uint64_t off = (uint64_t)hi_r * 4u + (uint32_t)lane * 16u;
+        if (off + 16u <= nb) glds16(src + off, lds_base + (uint32_t)r * kRowBytes + dst);
+        else if (off < nb) {   // the capture's last, incomplete 16 bytes: nothing past n_avail is read
+            for (uint32_t j = 0; off + 4u * j < nb; ++j)
+                *reinterpret_cast<int*>(lds + (uint32_t)r * kRowBytes + dst + (uint32_t)lane * 16u + 4u * j) =
+                    *reinterpret_cast<const __attribute__((address_space(1))) int*>(src + off + 4u * j);
+        }
+    };
     auto refill = [&](bool wants, uint32_t g, int max_rounds) {
         for (int rep = 0; rep < max_rounds; ++rep) {
             const bool need = wants && hi < g + kAheadMin && (uint64_t)hi * 4u < n_bytes;
@@ -233,10 +256,10 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if ((m >> (16 * r)) & 1ull) {      // wave-uniform
-                    if (row == r) {
-                        const uint32_t dst = (hi * 4u) & (kRingBytes - 1u);
-                        issue_block(dst);
-                        if (dst == 0u) issue_block(kRingBytes);   // ring head: mirror into the guard
+                    const uint32_t hi_r = (uint32_t)__builtin_amdgcn_readlane((int)hi, 16 * r);
+                    issue_wide(r, hi_r);
+                    if (((hi_r * 4u) & (kRingBytes - 1u)) == 0u) {   // ring head: mirror its first 64 samples into the guard
+                        if (row == r) issue_block(kRingBytes);
                     }
                 }
             }
@@ -386,7 +409,7 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
         pos = pos_next;
         first = false;
     };
-    refill(!done, origin + (uint32_t)(int)mu, 16);
+    refill(!done, origin + (uint32_t)(int)mu, 4);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();                     // atan table visible (single wave: LDS ordering only)
 
