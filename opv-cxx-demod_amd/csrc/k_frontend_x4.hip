@@ -10,14 +10,15 @@
 // reductions stay inside a DPP row (4 rotations, no cross-row swaps), and the per-sample work grows only
 // from one to four taps per lane. Rows reach their chunk ends, first symbols and refill points at different
 // symbols, so the loop carries per-row call state under exec masks; symbols run in BATCHES that provably need none
-// of it for any row (round 2: the same statements compiled without the tests), which took the per-wave-symbol count
-// (rocprofv3 PMC, MI355X, 4096 streams) from 448 VALU + 87 SALU + 12 LDS/VMEM to 372 + 57 + 9 = 110 issued
-// instructions per symbol and stream (one wave per stream: 166). Because a wave carries four streams the chip
-// fills four times later, and a launch lasts as long as one wave needs for its four streams: 68.7 ms for 30 frames
-// whether the context has 1025 or 4096 streams (four waves per workgroup = one per SIMD of a CU by construction, see
-// msk_frontend_x4_body), 99.7 ms for 8192 (two waves per SIMD): front-end alone 156 GS/s at 4096 streams, 214 at 8192.
-// The one-wave kernel runs 1024 streams at a time in 23.9 ms per 30 frames: faster up to 2048 streams, slower from
-// 2049 on, which is where the shim switches.
+// of it for any row (round 2: the same statements compiled without the tests), and the rings are refilled in 256-sample
+// blocks by the whole wave; together they took the per-wave-symbol count (rocprofv3 PMC, MI355X, 4096 streams) from
+// 448 VALU + 87 SALU + 12 LDS/VMEM to 360 + 28 + 9 = 99 issued instructions per symbol and stream (one wave per stream:
+// 166). Because a wave carries four streams the chip fills four times later, and a launch lasts as long as one wave
+// needs for its four streams: 57 ms for 30 frames whether the context has 1025 or 4096 streams (four waves per
+// workgroup = one per SIMD of a CU by construction, see msk_frontend_x4_body), 90 ms for 8192 (two waves per SIMD):
+// front-end alone 187 GS/s at 4096 streams, 238 at 8192 (round 1: 87 / 130). The one-wave kernel runs 1024 streams at a
+// time in 23.9 ms per 30 frames: faster up to 2048 streams, slower from 2049 on, which is where the shim switches
+// (DESIGN.md §3.1).
 //
 // Mapping (row r = lane / 16 serves stream 4*blockIdx.x + r, t = lane % 16):
 //   * lane t owns the interpolated samples Lam_j = L(pos + j - 10), j = t + 16 q, q = 0..3 (j < 60); the
@@ -61,8 +62,7 @@ constexpr uint32_t kBlock = 256;                    // samples per refill block 
 // overwrites samples below hi - 768 <= g - 120, which nothing reads any more. At most one block per row and refill point.
 constexpr uint32_t kAheadMin = 648;
 constexpr uint32_t kTabOff = 4 * kRowBytes;         // 17408
-constexpr uint32_t kTabRow = 10;
-// LDS per workgroup: WPB x kTabOff + the atan table = 20 048 B for one wave (eight workgroups per CU), 72 272 B for four (two)
+// LDS per workgroup: WPB x kTabOff + the atan table (129 x 64 B) = 25 664 B for one wave (six workgroups per CU), 77 888 B for four (two)
 static_assert(kTabOff % 16 == 0, "16-byte LDS alignment");
 
 typedef __attribute__((address_space(1))) double gdouble;
@@ -143,7 +143,7 @@ __device__ __noinline__ double2 silence_pd_x4(double dr, double di, double pa, d
 
 }  // namespace
 
-extern __constant__ double kOpvAtanTab[33][10];  // defined with k_frontend.hip (opv_atan2.h)
+extern __constant__ double kOpvAtanTabQ[129][8];  // defined with k_frontend.hip (opv_atan2.h)
 
 // WPB = wavefronts per workgroup (k_frontend.hip, msk_frontend_body: single-wave workgroups are placed without regard
 // to SIMDs, four waves of one workgroup always land on the four SIMDs of a CU). Waves share only the atan table.
@@ -155,10 +155,10 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
     const bool have = sidx < n_streams;
     OpvStream& st = streams[have ? sidx : n_streams - 1];   // idle rows read a valid record and never write
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[WPB * kTabOff + 33 * kTabRow * 8];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[WPB * kTabOff + 129 * 64];
     unsigned char* const lds = lds_all + wave * kTabOff;    // this wave's four rings
     double* atab = reinterpret_cast<double*>(lds_all + WPB * kTabOff);
-    for (int i = threadIdx.x; i < 33 * (int)kTabRow; i += 64 * WPB) atab[i] = (&kOpvAtanTab[0][0])[i];
+    for (int i = threadIdx.x; i < 129 * 8; i += 64 * WPB) atab[i] = (&kOpvAtanTabQ[0][0])[i];
     const unsigned char* ring = lds + (uint32_t)row * kRowBytes;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const uint32_t ring_lds = lds_base + (uint32_t)row * kRowBytes;
@@ -355,17 +355,16 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
         const double ar = fma(dr, prs, di * pis), ai = fma(di, prs, -(dr * pis));
         const double cy = fma(ar, pv.x40c, ai * pv.x40s);   // Im z
         const double cx = fma(ar, pv.x40s, -(ai * pv.x40c)); // Re z
-        const double ax = fabs(cx), ay = fabs(cy);
-        const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+        // the angle without an octant fix-up (opv_atan2.h: opv_atan2_q): atan(|cy| / |cx|) = pi/4 + atan(q),
+        // q = (|cy| - |cx|) / (|cy| + |cx|) in [-1, 1]
+        const double sum = fabs(cx) + fabs(cy), dif = fabs(cy) - fabs(cx);
         // ---- the two divides on one reciprocal ------------------------------------------------
-        const double dm = fmax(mx, 1e-100);
+        const double dm = sum + 1e-100;                     // the guard against digital silence: IS sum unless sum is 0 (k_frontend.hip)
         const double tt = den * dm;
         double y = __builtin_amdgcn_rcp(tt);
-        y = fma(fma(-tt, y, 1.0), y, y);
-        y = fma(fma(-tt, y, 1.0), y, y);
+        y = fma(fma(-tt, y, 1.0), y, y);                    // one Newton step (2^-24.4 -> 2^-48.7, scripts/microbench/rcp_accuracy.hip)
         const double iden = y * dm, idm = y * den;
-        double ratio = mn * idm;
-        ratio = fma(fma(-dm, ratio, mn), idm, ratio);
+        const double ratio = dif * idm;                     // good to 2^-48: 3.5e-15 rad on the angle
         double ted = num * iden;
         ted = fma(fma(-den, ted, num), iden, ted);
         // ---- timing loop (ref :283-286, :313) ------------------------------------------------
@@ -375,23 +374,21 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
         if ((uint32_t)t == slot) { held = soft; held_off = soft_off; held_valid = true; }
         // ---- AFC (ref :289-306): not on the first symbol of a call -------------------------------
         if (!kGeneric || !first) {
-            const double kd = rint(ratio * 32.0);
-            const int k = (int)kd;
-            const double h = fma(kd, -1.0 / 32.0, ratio);
-            const double* trow = atab + k * (int)kTabRow;
-            double pd = fma(trow[8], h, trow[7]);
-            pd = fma(pd, h, trow[6]);
+            // nearest expansion point k/64 by the 1.5 * 2^52 trick: the sum's low word is the row index k + 64
+            const double kt = fma(ratio, 64.0, 6755399441055744.0 + 64.0);
+            const double h = fma(kt - (6755399441055744.0 + 64.0), -1.0 / 64.0, ratio);   // |h| <= 1/128
+            const double* trow = atab + ((unsigned)dlo(kt) << 3);
+            double pd = fma(trow[7], h, trow[6]);               // degree 7: pi/4 + atan(q)
             pd = fma(pd, h, trow[5]);
             pd = fma(pd, h, trow[4]);
             pd = fma(pd, h, trow[3]);
             pd = fma(pd, h, trow[2]);
             pd = fma(pd, h, trow[1]);
             pd = fma(pd, h, trow[0]);
-            pd = (ay > ax) ? 1.57079632679489661923 - pd : pd;
             const double sx = mkd((dhi(cx) & (int)0x80000000) | 0x3ff00000, 0);
             pd = fma(sx, pd, fma(-sx, 1.57079632679489661923, 1.57079632679489661923));
             pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));
-            if (mx == 0.0) {                                 // digital silence on either side
+            if (sum == 0.0) {                                // digital silence on either side
                 const double2 sp = silence_pd_x4(dr, di, pv.a, pv.b, pv.c, pv.d, pv.x40c, pv.x40s, soft < 0.0, fo_sum,
                                                  (uint32_t)n_soft + (((soft_off - soft_off0) & soft_bmask) >> 3),
                                                  P1o, P2o, P3o, P4o);
