@@ -123,3 +123,35 @@ def test_512_stream_context_vs_oracle():
         total += len(fr)
     assert total >= S * (F - 1)
     dm.close()
+
+
+@pytest.mark.gpu
+def test_2060_stream_context_on_the_automatic_mapping():
+    """More streams than the one-wave-per-stream kernel holds in two rounds: the shim takes the four-per-wave mapping by
+    itself (from 2049 streams; 2060 = 128 full workgroups + a partly filled one, and the last wave has idle rows).
+    24 distinct captures (16 dB, different offsets / payloads) shared by the 2060 streams, every stream against the
+    oracle's result for its capture."""
+    import torch
+    from __graft_entry__ import load_opv_amd, load_pkg_module
+    from oracle_lib import Oracle
+    amd, workload = load_opv_amd(), load_pkg_module("workload")
+    dev = torch.device("cuda", 0)
+    S, D, F = 2060, 24, 3
+    n = amd.lib().opv_tx_modulated_samples(F)
+    dm = amd.Demod(S, max_samples=n + 64, streaming=True)
+    d_iq, tx, n = workload.generate(amd, dm, torch, dev, range(D), F, 16.0)
+    for k in range(S):
+        dm.attach(k, d_iq[k % D].data_ptr(), n, eof=True)
+    dm.process()
+    dm.sync()
+    host = d_iq.cpu().numpy()
+    o = Oracle()
+    exp = [o.receive(host[j], streaming=True, want_soft=False) for j in range(D)]
+    for k in range(S):
+        e = exp[k % D]
+        fr, meta = dm.pop_frames(k)
+        assert np.array_equal(fr, e["frames"]), k
+        assert np.array_equal(meta["viterbi_metric"], e["metrics"]) and np.array_equal(meta["release_symbol"], e["frame_sym"]), k
+        st = dm.state(k)
+        assert st.est_offset_hz == e["est_offset"] and st.total_symbols == e["n_soft"], k
+    dm.close()

@@ -1018,7 +1018,7 @@ def test_clock_rate_error_and_random_channels_fuzz(amd, oracle, iq10, iq100, see
 
 
 def test_four_streams_per_wave_mapping(amd, oracle, iq10, iq100):
-    """k_msk_frontend_x4 (four streams per wavefront, the mapping the shim picks from 8192 streams) on
+    """k_msk_frontend_x4 (four streams per wavefront, the mapping the shim picks from 2049 streams) on
     the cases that exercise its per-row machinery: rows with different chunk schedules (clock error,
     truncation), an idle row (stream count not a multiple of 4), the first-symbol early-gate clamp,
     the end-of-capture partial block, digital-silence gaps, batch mode, incremental pushes."""
