@@ -1023,6 +1023,16 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 if constexpr (kDual) { if (__builtin_expect(timeouts != 0u, 0)) break; }   // the partner wave never came
                 uint32_t pairs = uni(housekeeping(pos)) >> 1;
                 if constexpr (!kDual) fetch(pos, false);   // (dual: the margins of the tile events make the early fetch final)
+                if constexpr (RMAC) {
+                    // four symbols per trip: a taken branch costs a lone wave 36 cycles (scripts/microbench/dpp64.hip, empty loop)
+                    for (uint32_t quads = pairs >> 1; quads != 0u; --quads) {
+                        sym(TagSteady{}, qq, qp);
+                        sym(TagSteady{}, qp, qq);
+                        sym(TagSteady{}, qq, qp);
+                        sym(TagSteady{}, qp, qq);
+                    }
+                    pairs &= 1u;
+                }
                 for (; pairs != 0u; --pairs) {
                     sym(TagSteady{}, qq, qp);
                     sym(TagSteady{}, qp, qq);
