@@ -86,6 +86,24 @@ __device__ inline double row_sum(double v) {
     v = dpp_add<0x121>(v);
     return v;
 }
+// four row sums in lockstep: a DPP read needs two wait states behind the VALU write of its source, and one sum's rotation
+// steps are a dependent chain (hipcc pads every step with s_nop 1) - the other three sums' instructions fill the slots
+template <int CTRL>
+__device__ inline void dpp_add4(double& a, double& b, double& c, double& d) {
+    const int al = __builtin_amdgcn_mov_dpp(dlo(a), CTRL, 0xF, 0xF, true), ah = __builtin_amdgcn_mov_dpp(dhi(a), CTRL, 0xF, 0xF, true);
+    const int bl = __builtin_amdgcn_mov_dpp(dlo(b), CTRL, 0xF, 0xF, true), bh = __builtin_amdgcn_mov_dpp(dhi(b), CTRL, 0xF, 0xF, true);
+    const int cl = __builtin_amdgcn_mov_dpp(dlo(c), CTRL, 0xF, 0xF, true), ch = __builtin_amdgcn_mov_dpp(dhi(c), CTRL, 0xF, 0xF, true);
+    const int dl = __builtin_amdgcn_mov_dpp(dlo(d), CTRL, 0xF, 0xF, true), dh = __builtin_amdgcn_mov_dpp(dhi(d), CTRL, 0xF, 0xF, true);
+    __builtin_amdgcn_sched_barrier(0);
+    a += mkd(ah, al); b += mkd(bh, bl); c += mkd(ch, cl); d += mkd(dh, dl);
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ inline void row_sum4(double& a, double& b, double& c, double& d) {
+    dpp_add4<0x128>(a, b, c, d);
+    dpp_add4<0x124>(a, b, c, d);
+    dpp_add4<0x122>(a, b, c, d);
+    dpp_add4<0x121>(a, b, c, d);
+}
 __device__ inline double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 // exp(j x), |x| <= 0.284: same near-minimax pair as k_frontend.hip (abs error 1e-19 / 1.3e-18)
@@ -336,7 +354,8 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
             if (q > 0) { lA = fma(zr, aL[q], lA); lB = fma(zi, aL[q], lB); lC = fma(zi, bL[q], lC); lD = fma(zr, bL[q], lD); }
         }
         // ---- on-time gate: soft value, dominant tone (ref :264-272) --------------------------
-        const double P1o = row_sum(o1), P2o = row_sum(o2), P3o = row_sum(o3), P4o = row_sum(o4);
+        row_sum4(o1, o2, o3, o4);
+        const double P1o = o1, P2o = o2, P3o = o3, P4o = o4;
         const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;
         const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;
         const double en1 = fma(s1r_, s1r_, s1i_ * s1i_);
@@ -345,8 +364,8 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
         const double nsg = mkd((dhi(soft) & (int)0x80000000) | 0x3ff00000, 0);  // -1 iff tone 1 dominates
         const double sg = -nsg;
         // ---- early / late gates of the dominant tone (ref :271-280) ---------------------------
-        const double Ere = row_sum(fma(sg, eC, eA)), Eim = row_sum(fma(-sg, eD, eB));
-        const double Lre = row_sum(fma(sg, lC, lA)), Lim = row_sum(fma(-sg, lD, lB));
+        double Ere = fma(sg, eC, eA), Eim = fma(-sg, eD, eB), Lre = fma(sg, lC, lA), Lim = fma(-sg, lD, lB);
+        row_sum4(Ere, Eim, Lre, Lim);
         const double ee = fma(Ere, Ere, Eim * Eim), el = fma(Lre, Lre, Lim * Lim);
         const double num = el - ee, den = el + ee + 1e-10;
         // ---- phase detector operands: dom * conj(prev) (ref :289-299, see k_frontend.hip) -----
@@ -365,26 +384,32 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
         y = fma(fma(-tt, y, 1.0), y, y);                    // one Newton step (2^-24.4 -> 2^-48.7, scripts/microbench/rcp_accuracy.hip)
         const double iden = y * dm, idm = y * den;
         const double ratio = dif * idm;                     // good to 2^-48: 3.5e-15 rad on the angle
+        // the angle's table row is requested here and used after the timing loop: with one wave per SIMD nothing else
+        // covers the LDS round trip (the row index is in range on every path: |ratio| <= 1)
+        // nearest expansion point k/64 by the 1.5 * 2^52 trick: the sum's low word is the row index k + 64
+        const double kt = fma(ratio, 64.0, 6755399441055744.0 + 64.0);
+        const double h = fma(kt - (6755399441055744.0 + 64.0), -1.0 / 64.0, ratio);   // |h| <= 1/128
+        const double2* trow = reinterpret_cast<const double2*>(atab + ((unsigned)dlo(kt) << 3));
+        const double2 c67 = trow[3], c45 = trow[2], c23 = trow[1], c01 = trow[0];
+        __builtin_amdgcn_sched_barrier(0);
         double ted = num * iden;
         ted = fma(fma(-den, ted, num), iden, ted);
         // ---- timing loop (ref :283-286, :313) ------------------------------------------------
         tf = clampd(fma(0.00001, ted, tf), -0.1, 0.1);
         const double adj = fma(0.005, ted, tf);   // |adj| <= 0.105: the reference's clamp to +/-2 (:286) cannot act, see k_frontend.hip
-        const double pos_next = pos + (40.0 + adj);
+        double pos_next = pos + (40.0 + adj);
         if ((uint32_t)t == slot) { held = soft; held_off = soft_off; held_valid = true; }
+        asm volatile("" : "+v"(pos_next), "+v"(tf), "+v"(held));   // (keeps these statements HERE: hipcc otherwise sinks them below the AFC block)
+        __builtin_amdgcn_sched_barrier(0);
         // ---- AFC (ref :289-306): not on the first symbol of a call -------------------------------
         if (!kGeneric || !first) {
-            // nearest expansion point k/64 by the 1.5 * 2^52 trick: the sum's low word is the row index k + 64
-            const double kt = fma(ratio, 64.0, 6755399441055744.0 + 64.0);
-            const double h = fma(kt - (6755399441055744.0 + 64.0), -1.0 / 64.0, ratio);   // |h| <= 1/128
-            const double* trow = atab + ((unsigned)dlo(kt) << 3);
-            double pd = fma(trow[7], h, trow[6]);               // degree 7: pi/4 + atan(q)
-            pd = fma(pd, h, trow[5]);
-            pd = fma(pd, h, trow[4]);
-            pd = fma(pd, h, trow[3]);
-            pd = fma(pd, h, trow[2]);
-            pd = fma(pd, h, trow[1]);
-            pd = fma(pd, h, trow[0]);
+            double pd = fma(c67.y, h, c67.x);                   // degree 7: pi/4 + atan(q)
+            pd = fma(pd, h, c45.y);
+            pd = fma(pd, h, c45.x);
+            pd = fma(pd, h, c23.y);
+            pd = fma(pd, h, c23.x);
+            pd = fma(pd, h, c01.y);
+            pd = fma(pd, h, c01.x);
             const double sx = mkd((dhi(cx) & (int)0x80000000) | 0x3ff00000, 0);
             pd = fma(sx, pd, fma(-sx, 1.57079632679489661923, 1.57079632679489661923));
             pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));
