@@ -314,6 +314,7 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
             w0[q] = tap[0];
             w1[q] = tap[1];
         }
+        __builtin_amdgcn_sched_barrier(0);                              // taps requested FIRST, the LO under their latency
         if (kGeneric && first && pf < 0.0) {                           // early gate before the chunk: s[0] (ref :237)
             const int s0 = *reinterpret_cast<const int*>(ring + ((origin << 2) & (kRingBytes - 1u)));
             w0[0] = s0;
@@ -338,6 +339,10 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
             for (int q = 0; q < 4; ++q) sincos((kfs0 + (16.0 * q) * kDeltaPerHz) * fo, &xs[q], &xc[q]);
             sincos((40.0 * kDeltaPerHz) * fo, &x40s, &x40c);
         }
+        // (the LO above does not depend on the taps: it stays between their LDS reads and their first use - left to
+        // itself hipcc unpacks the taps first and waits for them)
+        asm volatile("" : "+v"(xs[3]), "+v"(xc[3]), "+v"(x40s), "+v"(x40c));
+        __builtin_amdgcn_sched_barrier(0);
 
         double o1 = 0, o2 = 0, o3 = 0, o4 = 0;             // on-time P1..P4 partials
         double eA = 0, eB = 0, eC = 0, eD = 0, lA = 0, lB = 0, lC = 0, lD = 0;
