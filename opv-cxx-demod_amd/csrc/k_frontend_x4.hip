@@ -5,7 +5,7 @@
 // (opv_capi.hip: opv_set_frontend / automatic from 2049 streams).
 //
 // Why: a symbol's loop filters, divides and atan2 are scalar work per STREAM. With one stream per
-// wave they are executed on 64 lanes for one result (about 65 of that kernel's 166 instructions per
+// wave they are executed on 64 lanes for one result (about 65 of that kernel's 164 instructions per
 // symbol). Here a wave instruction advances four streams: the scalar tail is shared by four, the
 // reductions stay inside a DPP row (4 rotations, no cross-row swaps), and the per-sample work grows only
 // from one to four taps per lane. Rows reach their chunk ends, first symbols and refill points at different
@@ -13,7 +13,7 @@
 // of it for any row (round 2: the same statements compiled without the tests), and the rings are refilled in 256-sample
 // blocks by the whole wave; together they took the per-wave-symbol count (rocprofv3 PMC, MI355X, 4096 streams) from
 // 448 VALU + 87 SALU + 12 LDS/VMEM to 349 + 25 + 8 = 96 issued instructions per symbol and stream (one wave per stream:
-// 166). Because a wave carries four streams the chip fills four times later, and a launch lasts as long as one wave
+// 164). Because a wave carries four streams the chip fills four times later, and a launch lasts as long as one wave
 // needs for its four streams: 53 ms for 30 frames whether the context has 1025 or 4096 streams (four waves per
 // workgroup = one per SIMD of a CU by construction, see msk_frontend_x4_body), 86 ms for 8192 (two waves per SIMD):
 // front-end alone 203 GS/s at 4096 streams, 248 at 8192 (round 1: 87 / 130). The one-wave kernel runs 1024 streams at a
