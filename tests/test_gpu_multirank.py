@@ -126,17 +126,19 @@ def test_512_stream_context_vs_oracle():
 
 
 @pytest.mark.gpu
-def test_2060_stream_context_on_the_automatic_mapping():
-    """More streams than the one-wave-per-stream kernel holds in two rounds: the shim takes the four-per-wave mapping by
-    itself (from 2049 streams; 2060 = 128 full workgroups + a partly filled one, and the last wave has idle rows).
-    24 distinct captures (16 dB, different offsets / payloads) shared by the 2060 streams, every stream against the
-    oracle's result for its capture."""
+@pytest.mark.parametrize("S", [522, 2060])
+def test_many_stream_contexts_on_the_automatic_mapping(S):
+    """522 streams: one wave per stream, FOUR waves per workgroup (k_msk_frontend_rb_wg4, from 513 streams; 130 full
+    workgroups + a partly filled one). 2060 streams: more than the one-wave-per-stream kernel holds in two rounds, the
+    shim takes the four-per-wave mapping by itself (from 2049 streams; 128 full workgroups + a partly filled one, and
+    the last wave has idle rows). 24 distinct captures (16 dB, different offsets / payloads) shared by the streams,
+    every stream against the oracle's result for its capture."""
     import torch
     from __graft_entry__ import load_opv_amd, load_pkg_module
     from oracle_lib import Oracle
     amd, workload = load_opv_amd(), load_pkg_module("workload")
     dev = torch.device("cuda", 0)
-    S, D, F = 2060, 24, 3
+    D, F = 24, 3
     n = amd.lib().opv_tx_modulated_samples(F)
     dm = amd.Demod(S, max_samples=n + 64, streaming=True)
     d_iq, tx, n = workload.generate(amd, dm, torch, dev, range(D), F, 16.0)
