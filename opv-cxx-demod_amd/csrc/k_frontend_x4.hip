@@ -98,11 +98,26 @@ __device__ inline void dpp_add4(double& a, double& b, double& c, double& d) {
     a += mkd(ah, al); b += mkd(bh, bl); c += mkd(ch, cl); d += mkd(dh, dl);
     __builtin_amdgcn_sched_barrier(0);
 }
-__device__ inline void row_sum4(double& a, double& b, double& c, double& d) {
+// Two rotation steps leave the row's four partial sums in its lanes 0..3 (every lane l holds the one of l mod 4); the
+// DP-ALU DPP forms finish the job in 16 instructions instead of the 24 of two more rotation steps: v_mov_b64_dpp
+// row_newbcast:0 + three v_fmac_f64_dpp row_newbcast:n with a factor of 1.0 per value (k_frontend.hip: symbol_r,
+// scripts/microbench/dpp64.hip). The four adds of the step before are the wait states the first DPP reads need.
+__device__ inline void row_sum4(double& a, double& b, double& c, double& d, double one) {
     dpp_add4<0x128>(a, b, c, d);
     dpp_add4<0x124>(a, b, c, d);
-    dpp_add4<0x122>(a, b, c, d);
-    dpp_add4<0x121>(a, b, c, d);
+    double ra, rb, rc, rd;
+#define OPV_B4(N) "v_fmac_f64_dpp %0, %4, %8 row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t" \
+                  "v_fmac_f64_dpp %1, %5, %8 row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t" \
+                  "v_fmac_f64_dpp %2, %6, %8 row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t" \
+                  "v_fmac_f64_dpp %3, %7, %8 row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+    asm("v_mov_b64_dpp %0, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %1, %5 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %2, %6 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b64_dpp %3, %7 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        OPV_B4(1) OPV_B4(2) OPV_B4(3)
+        : "=&v"(ra), "=&v"(rb), "=&v"(rc), "=&v"(rd) : "v"(a), "v"(b), "v"(c), "v"(d), "v"(one));
+#undef OPV_B4
+    a = ra; b = rb; c = rc; d = rd;
 }
 __device__ inline double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
@@ -195,6 +210,8 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
     const double kf0 = (double)(t - 10);
     const double kfs0 = kf0 * kDeltaPerHz;
     const double kgain = st.afc_alpha * (kSymRate / kTwoPi);
+    double kc_one = 1.0;                                // the broadcast FMACs' second factor has to be a VGPR
+    asm volatile("" : "+v"(kc_one));
 
     // ---- carry (row-uniform, in VGPRs) ----------------------------------------------------------
     double fo = st.freq_offset, tf = st.timing_freq, mu = st.mu, fo_sum = st.fo_sum;
@@ -359,7 +376,7 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
             if (q > 0) { lA = fma(zr, aL[q], lA); lB = fma(zi, aL[q], lB); lC = fma(zi, bL[q], lC); lD = fma(zr, bL[q], lD); }
         }
         // ---- on-time gate: soft value, dominant tone (ref :264-272) --------------------------
-        row_sum4(o1, o2, o3, o4);
+        row_sum4(o1, o2, o3, o4, kc_one);
         const double P1o = o1, P2o = o2, P3o = o3, P4o = o4;
         const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;
         const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;
@@ -370,7 +387,7 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
         const double sg = -nsg;
         // ---- early / late gates of the dominant tone (ref :271-280) ---------------------------
         double Ere = fma(sg, eC, eA), Eim = fma(-sg, eD, eB), Lre = fma(sg, lC, lA), Lim = fma(-sg, lD, lB);
-        row_sum4(Ere, Eim, Lre, Lim);
+        row_sum4(Ere, Eim, Lre, Lim, kc_one);
         const double ee = fma(Ere, Ere, Eim * Eim), el = fma(Lre, Lre, Lim * Lim);
         const double num = el - ee, den = el + ee + 1e-10;
         // ---- phase detector operands: dom * conj(prev) (ref :289-299, see k_frontend.hip) -----
