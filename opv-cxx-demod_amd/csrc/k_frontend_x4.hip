@@ -346,19 +346,19 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
             xc[q] = fma(xc[q - 1], c16, -(xs[q - 1] * s16));
             xs[q] = fma(xc[q - 1], s16, xs[q - 1] * c16);
         }
-        // X[40] = exp(j 40 d): uniform per row, needed by the NEXT symbol's phase detector
-        double x40s, x40c;
-        expj_small((40.0 * kDeltaPerHz) * fo, x40s, x40c);
         if (kGeneric && fabs(fo) > 2000.0) {
             // -o takes any value (ref :1004-1005) and the AFC clamp (:303) first acts at the END of the
             // call's second symbol: outside the polynomial's range those symbols take the full-range routine
 #pragma unroll
             for (int q = 0; q < 4; ++q) sincos((kfs0 + (16.0 * q) * kDeltaPerHz) * fo, &xs[q], &xc[q]);
-            sincos((40.0 * kDeltaPerHz) * fo, &x40s, &x40c);
         }
+        // X[40] = exp(j 40 d), needed by the NEXT symbol's phase detector: it is lane 2's fourth tap (m = 2 - 10 + 48),
+        // handed to the row by v_mov_b64_dpp row_newbcast:2 (`old` operands: the two dead X[16] registers)
+        const double x40c = __builtin_amdgcn_update_dpp(c16, xc[3], 0x152, 0xF, 0xF, false);
+        const double x40s = __builtin_amdgcn_update_dpp(s16, xs[3], 0x152, 0xF, 0xF, false);
         // (the LO above does not depend on the taps: it stays between their LDS reads and their first use - left to
         // itself hipcc unpacks the taps first and waits for them)
-        asm volatile("" : "+v"(xs[3]), "+v"(xc[3]), "+v"(x40s), "+v"(x40c));
+        asm volatile("" : "+v"(xs[3]), "+v"(xc[3]));
         __builtin_amdgcn_sched_barrier(0);
 
         double o1 = 0, o2 = 0, o3 = 0, o4 = 0;             // on-time P1..P4 partials
