@@ -158,6 +158,17 @@ def test_afc_alpha_flag(amd, oracle, iq10):
     d.close()
 
 
+def test_set_frontend_accepts_the_documented_mappings_only(amd):
+    """opv_set_frontend: 0 (automatic), 1, 4, -1, -2 (include/opv_demod.h); anything else is OPV_EINVAL with a message."""
+    d = amd.Demod(1, max_samples=1 << 16, streaming=True)
+    for ok in (0, 1, 4, -1, -2, 0):
+        d.set_frontend(ok)
+    for bad in (2, 3, -3, 8, 64):
+        with pytest.raises(amd.OpvError, match="opv_set_frontend"):
+            d.set_frontend(bad)
+    d.close()
+
+
 @pytest.mark.parametrize("mapping", [-2, -1])
 def test_comparison_mappings_are_exact(amd, oracle, iq10, iq100, mapping):
     """The two one-stream mappings kept for comparison, never selected automatically. opv_set_frontend(-2): the timing loop
