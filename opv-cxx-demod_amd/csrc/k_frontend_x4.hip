@@ -176,7 +176,11 @@ __device__ __noinline__ double2 silence_pd_x4(double dr, double di, double pa, d
 
 }  // namespace
 
-extern __constant__ double kOpvAtanTabQ[129][8];  // defined with k_frontend.hip (opv_atan2.h)
+// this translation unit's own image of the angle table (opv_atan2.h: kOpvAtanTabQ): every .hip file is compiled to a
+// code object of its own (no relocatable device code), so that the two front-end files can go through tools/align_vop3.py
+__constant__ double kOpvAtanTabQx4[129][8] = {
+#include "opv_atan_table_q.inc"
+};
 
 // WPB = wavefronts per workgroup (k_frontend.hip, msk_frontend_body: single-wave workgroups are placed without regard
 // to SIMDs, four waves of one workgroup always land on the four SIMDs of a CU). Waves share only the atan table.
@@ -191,7 +195,7 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[WPB * kTabOff + 129 * 64];
     unsigned char* const lds = lds_all + wave * kTabOff;    // this wave's four rings
     double* atab = reinterpret_cast<double*>(lds_all + WPB * kTabOff);
-    for (int i = threadIdx.x; i < 129 * 8; i += 64 * WPB) atab[i] = (&kOpvAtanTabQ[0][0])[i];
+    for (int i = threadIdx.x; i < 129 * 8; i += 64 * WPB) atab[i] = (&kOpvAtanTabQx4[0][0])[i];
     const unsigned char* ring = lds + (uint32_t)row * kRowBytes;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const uint32_t ring_lds = lds_base + (uint32_t)row * kRowBytes;

@@ -11,7 +11,7 @@
 
 template <int KIND>
 __global__ void k(double* out, unsigned long long* cyc, int rep, unsigned long long mask) {
-    double* po = out + threadIdx.x;                       // every per-lane address exists BEFORE the mask changes: hipcc does not
+    double* po = out + blockIdx.x * 64 + threadIdx.x;                       // every per-lane address exists BEFORE the mask changes: hipcc does not
     double a = *po, b = 1.0000001, c = 1e-9;              // know about the s_mov to exec and may move VALU code across it
     float af = (float)a, bf = 1.0000001f, cf = 1e-9f;
     asm volatile("" : "+v"(po), "+v"(a), "+v"(af), "+v"(b), "+v"(c), "+v"(bf), "+v"(cf));
@@ -26,12 +26,12 @@ __global__ void k(double* out, unsigned long long* cyc, int rep, unsigned long l
     asm volatile("s_mov_b64 exec, %0" : : "s"(keep));
     asm volatile("" : "+v"(po), "+v"(a), "+v"(af));
     *po = a + af;
-    if (threadIdx.x == 0) cyc[0] = t1 - t0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
 int main() {
     double* d; unsigned long long* c;
-    hipMalloc(&d, 64 * 8); hipMalloc(&c, 8);
+    hipMalloc(&d, 64 * 64 * 8); hipMalloc(&c, 8);
     std::vector<double> h(64, 1.0);
     const unsigned long long masks[3] = {~0ull, 0xFFFFull, 1ull};
     const char* names[3] = {"64 lanes", "16 lanes (one row)", "1 lane"};
@@ -45,5 +45,16 @@ int main() {
             unsigned long long cy; hipMemcpy(&cy, c, 8, hipMemcpyDeviceToHost);
             printf("%-8s EXEC = %-20s %6.2f cycles per instruction (64 dependent per pass, loop included)\n", kind ? "fma_f32" : "fma_f64", names[m], (double)cy / 2000 / 64);
         }
+    // the same launch twelve times over: does the figure depend on anything but the code?
+    for (int grid : {1, 64}) {
+        printf("fma_f64, 64 lanes, %d workgroup(s), twelve launches:", grid);
+        for (int i = 0; i < 12; ++i) {
+            k<0><<<grid, 64>>>(d, c, 2000, ~0ull);
+            hipDeviceSynchronize();
+            unsigned long long cy; hipMemcpy(&cy, c, 8, hipMemcpyDeviceToHost);
+            printf(" %.2f", (double)cy / 2000 / 64);
+        }
+        printf("\n");
+    }
     return 0;
 }
