@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""align_vop3.py in.s out.s — keep 8-byte instructions of a gfx950 kernel on 8-byte addresses.
+
+Why: a LONE wave on a SIMD (the MSK front-end's regime: one wave per stream) pays about one cycle more for every
+8-byte instruction (VOP3, DPP, SDWA, DS, FLAT ...) that starts at an address of 4 mod 8
+(scripts/microbench/loop_align.hip: 4.5 vs 5.5 cycles per dependent v_fma_f64, period 8 bytes). hipcc shrinks every
+VOP1 / VOP2 / VOPC instruction it can to its 4-byte `_e32` encoding, so the parity flips all over a loop body: in the
+front-end's symbol loop 46 % of the 8-byte instructions sat on the wrong parity.
+
+What: device assembly in (`hipcc --cuda-device-only -S`), device assembly out. The input is assembled once to learn every
+instruction's address and size (llvm-objdump). Then, function by function, each run of 4-byte instructions that would
+leave the next 8-byte instruction misaligned gets ONE of its shrinkable members re-encoded as `_e64` (same operation,
+same operands, 8 bytes): no instruction is added, none is moved. Runs without a shrinkable member (s_nop, s_waitcnt,
+branches only) are left alone. The output is assembled again as a check; an `_e64` form the assembler rejects is
+blacklisted and the pass repeated.
+"""
+import re
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+LLVM = Path("/opt/rocm/lib/llvm/bin")
+TARGET = ["-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950"]
+
+
+def assemble(src, obj):
+    return subprocess.run([str(LLVM / "clang"), "-x", "assembler", *TARGET, "-c", str(src), "-o", str(obj)],
+                          capture_output=True, text=True)
+
+
+def disassemble(obj):
+    """{function: [(address, size, mnemonic)]} in address order"""
+    out = subprocess.run([str(LLVM / "llvm-objdump"), "-d", str(obj)], capture_output=True, text=True, check=True).stdout
+    funcs, cur = {}, None
+    for line in out.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+            continue
+        m = re.match(r"^\s+(\S+).*//\s*([0-9A-F]+):", line)
+        if m and cur is not None:
+            cur.append([int(m.group(2), 16), 0, m.group(1)])
+    for ins in funcs.values():
+        for a, b in zip(ins, ins[1:]):
+            a[1] = b[0] - a[0]
+        if ins:
+            ins[-1][1] = 4                      # s_endpgm / trailing s_nop
+    return funcs
+
+
+def instruction_lines(lines):
+    """{function: [line index]}: the lines of each function that assemble to one instruction"""
+    funcs, cur = {}, None
+    for i, raw in enumerate(lines):
+        s = raw.strip()
+        m = re.match(r"^([A-Za-z_][\w$.]*):", s)
+        if m and not s.startswith(".L"):
+            cur = funcs.setdefault(m.group(1), [])
+            continue
+        if s.startswith(".Lfunc_end"):
+            cur = None
+            continue
+        if cur is None or not s or s[0] in ";.#" or s.endswith(":"):
+            continue
+        if re.match(r"^\.?L[\w$.]*:", s):
+            continue
+        cur.append(i)
+    return funcs
+
+
+def mnemonic(line):
+    return line.strip().split()[0]
+
+
+def widen(line):
+    """the same instruction in its 8-byte VOP3 encoding"""
+    m = re.match(r"^(\s*)(\S+)(.*)$", line)
+    mn = m.group(2)
+    mn = mn[:-4] + "_e64" if mn.endswith("_e32") else mn + "_e64"
+    return m.group(1) + mn + m.group(3)
+
+
+def flexible(src_mn, dis_mn, size):
+    if size != 4 or not dis_mn.endswith("_e32"):
+        return False
+    if not dis_mn.startswith("v_"):
+        return False
+    if src_mn.endswith("_e64") or "_dpp" in src_mn or "_sdwa" in src_mn:
+        return False
+    return True
+
+
+def base(mn):
+    return re.sub(r"_e(32|64)$", "", mn)
+
+
+def same_instructions(ins, idx, lines):
+    return all(base(mnemonic(lines[i])) == base(x[2]) for x, i in zip(ins, idx))
+
+
+def plan(ins, lines_idx, lines, banned):
+    """indices (into ins) of the instructions to widen"""
+    flips, shift, run = [], 0, []
+    for k, (addr, size, dis_mn) in enumerate(ins):
+        a = addr + shift
+        if size == 4:
+            if k not in banned and flexible(mnemonic(lines[lines_idx[k]]), dis_mn, size):
+                run.append(k)
+            continue
+        if size % 8 == 0 and a % 8 == 4 and run:
+            flips.append(run.pop())
+            shift += 4
+        run = []
+    return flips
+
+
+def stats(ins):
+    eight = [x for x in ins if x[1] == 8]
+    return len(eight), sum(1 for x in eight if x[0] % 8 == 4)
+
+
+def main():
+    src, dst = Path(sys.argv[1]), Path(sys.argv[2])
+    lines = src.read_text().split("\n")
+    with tempfile.TemporaryDirectory() as td:
+        obj = Path(td) / "a.o"
+        r = assemble(src, obj)
+        if r.returncode:
+            sys.exit("align_vop3: the input does not assemble:\n" + r.stderr)
+        before = disassemble(obj)
+        where = instruction_lines(lines)
+        banned = {f: set() for f in before}
+        for attempt in range(40):
+            out = list(lines)
+            flipped = {}
+            for f, ins in before.items():
+                idx = where.get(f)
+                if idx is None or len(idx) > len(ins) or not same_instructions(ins, idx, lines):
+                    continue                    # not a function of this file's text (or no 1:1 match): left untouched
+                ins = ins[:len(idx)]            # (behind s_endpgm the object carries padding up to the next function)
+                fl = plan(ins, idx, lines, banned[f])
+                for k in fl:
+                    out[idx[k]] = widen(lines[idx[k]])
+                flipped[f] = fl
+            tmp = Path(td) / "b.s"
+            tmp.write_text("\n".join(out))
+            r = assemble(tmp, obj)
+            if r.returncode == 0:
+                break
+            bad = {int(m.group(1)) - 1 for m in re.finditer(r"b\.s:(\d+):\d+: error", r.stderr)}
+            if not bad:
+                sys.exit("align_vop3: the output does not assemble:\n" + r.stderr)
+            for f, fl in flipped.items():
+                for k in fl:
+                    if where[f][k] in bad:
+                        banned[f].add(k)
+        else:
+            sys.exit("align_vop3: no assembling output after 40 attempts")
+        after = disassemble(obj)
+        dst.write_text("\n".join(out))
+        for f in before:
+            if f in flipped:
+                n0, m0 = stats(before[f])
+                n1, m1 = stats(after[f])
+                if n0 > 200:
+                    print(f"align_vop3: {f}: {len(flipped[f])} instructions widened, misaligned 8-byte instructions {m0} -> {m1} of {n1}")
+
+
+if __name__ == "__main__":
+    main()
