@@ -8,10 +8,10 @@ VOP1 / VOP2 / VOPC instruction it can to its 4-byte `_e32` encoding, so the pari
 front-end's symbol loop 46 % of the 8-byte instructions sat on the wrong parity.
 
 What: device assembly in (`hipcc --cuda-device-only -S`), device assembly out. The input is assembled once to learn every
-instruction's address and size (llvm-objdump). Then, function by function, each run of 4-byte instructions that would
-leave the next 8-byte instruction misaligned gets ONE of its shrinkable members re-encoded as `_e64` (same operation,
-same operands, 8 bytes): no instruction is added, none is moved. Runs without a shrinkable member (s_nop, s_waitcnt,
-branches only) are left alone. The output is assembled again as a check; an `_e64` form the assembler rejects is
+instruction's address and size (llvm-objdump). Then, function by function, runs of 4-byte instructions get ONE of their
+shrinkable members re-encoded as `_e64` (same operation, same operands, 8 bytes) where that lowers the number of 8-byte
+instructions on the wrong parity (a dynamic programme over the function: runs without a shrinkable member - s_nop,
+s_waitcnt, branches only - pass their parity on). No instruction is added, none is moved. The output is assembled again as a check; an `_e64` form the assembler rejects is
 blacklisted and the pass repeated.
 """
 import re
@@ -100,18 +100,50 @@ def same_instructions(ins, idx, lines):
 
 
 def plan(ins, lines_idx, lines, banned):
-    """indices (into ins) of the instructions to widen"""
-    flips, shift, run = [], 0, []
-    for k, (addr, size, dis_mn) in enumerate(ins):
-        a = addr + shift
-        if size == 4:
-            if k not in banned and flexible(mnemonic(lines[lines_idx[k]]), dis_mn, size):
-                run.append(k)
+    """indices (into ins) of the instructions to widen: the function as alternating runs of 4-byte instructions and
+    blocks of 8-byte ones; a run with a shrinkable member may or may not add 4 bytes; dynamic programme over the parity
+    (0 / 4) at which each block starts, cost = number of 8-byte instructions that start at 4 mod 8"""
+    segs = []                                   # [first 8-byte index or None, n8, flexible member or None, bytes of the run]
+    run_bytes, flex = 0, None
+    parity0 = ins[0][0] % 8 if ins else 0
+    k = 0
+    while k < len(ins):
+        size = ins[k][1]
+        if size % 8:                            # 4-byte (or 12-byte) instruction: part of a run
+            run_bytes += size
+            if size == 4 and k not in banned and flexible(mnemonic(lines[lines_idx[k]]), ins[k][2], size):
+                flex = k
+            k += 1
             continue
-        if size % 8 == 0 and a % 8 == 4 and run:
-            flips.append(run.pop())
-            shift += 4
-        run = []
+        n8 = 0
+        while k < len(ins) and ins[k][1] % 8 == 0:
+            n8 += ins[k][1] // 8
+            k += 1
+        segs.append((n8, flex, run_bytes))
+        run_bytes, flex = 0, None
+    INF = 1 << 30
+    cost = {parity0: 0}
+    back = []
+    for n8, flex, rb in segs:
+        nxt, choice = {}, {}
+        for p, c in cost.items():
+            for add in ((0, 4) if flex is not None else (0,)):
+                q = (p + rb + add) % 8
+                cc = c + (n8 if q == 4 else 0)
+                if cc < nxt.get(q, INF):
+                    nxt[q] = cc
+                    choice[q] = (p, add)
+        cost = nxt
+        back.append(choice)
+    if not cost:
+        return []
+    q = min(cost, key=cost.get)
+    flips = []
+    for (n8, flex, rb), choice in zip(reversed(segs), reversed(back)):
+        p, add = choice[q]
+        if add:
+            flips.append(flex)
+        q = p
     return flips
 
 
