@@ -14,10 +14,10 @@
 // blocks by the whole wave, the row sums run four in lockstep and finish with broadcast FMACs; together they took the per-wave-symbol count (rocprofv3 PMC, MI355X, 4096 streams) from
 // 448 VALU + 87 SALU + 12 LDS/VMEM to 321 + 25 + 8 = 89 issued instructions per symbol and stream (one wave per stream:
 // 164). Because a wave carries four streams the chip fills four times later, and a launch lasts as long as one wave
-// needs for its four streams: 49 ms for 30 frames whether the context has 1025 or 4096 streams (four waves per
+// needs for its four streams: 47.5 ms for 30 frames whether the context has 1025 or 4096 streams (four waves per
 // workgroup = one per SIMD of a CU by construction, see msk_frontend_x4_body), 81 ms for 8192 (two waves per SIMD):
-// front-end alone 219 GS/s at 4096 streams, 263 at 8192 (round 1: 87 / 130). The one-wave kernel runs 1024 streams at a
-// time in 23.9 ms per 30 frames: faster up to 2048 streams, slower from 2049 on, which is where the shim switches
+// front-end alone 225 GS/s at 4096 streams, 265 at 8192 (round 1: 87 / 130). The one-wave kernel runs 1024 streams at a
+// time in 23 ms per 30 frames: faster up to 2048 streams, slower from 2049 on, which is where the shim switches
 // (DESIGN.md §3.1).
 //
 // Mapping (row r = lane / 16 serves stream 4*blockIdx.x + r, t = lane % 16):

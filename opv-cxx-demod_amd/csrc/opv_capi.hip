@@ -55,7 +55,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 // double up on SIMDs (k_frontend.hip: msk_frontend_body)
 constexpr int kFrontendWg4MinStreams = 512;
 constexpr int kFrontendX4Wg4MaxStreams = 8192;   // 2048 waves = two 80 KB workgroups per CU; beyond that single-wave workgroups (20 KB)
-constexpr int kFrontendX4MinStreams = 2049;      // measured on MI355X: one wave per stream runs 1024 streams at a time (47.8 ms per 2048 x 30 frames, 71 ms from 2049 on), four per wave 4096 (49 ms)
+constexpr int kFrontendX4MinStreams = 2049;      // measured on MI355X: one wave per stream runs 1024 streams at a time (46 ms per 2048 x 30 frames, 69 ms from 2049 on), four per wave 4096 (47.5 ms)
 
 struct StreamIn {  // host -> device per-round update
     const int16_t* iq;
