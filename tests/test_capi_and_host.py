@@ -126,3 +126,27 @@ def test_bench_starts_its_own_ranks_and_fails_loudly_without_gpus():
     env["WORLD_SIZE"] = "4"
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
     assert p.returncode == 2 and "disagrees with WORLD_SIZE=4" in p.stderr
+
+
+def test_alignment_pass_changes_encodings_only(amd):
+    """tools/align_vop3.py (the pass between `hipcc -S` and the assembler for the two front-end files): its output is its
+    input line for line, except that some instructions carry `_e64` where they carried `_e32` or no suffix - nothing
+    added, nothing moved, no operand touched - and the shipped library was built from that output."""
+    import subprocess
+    pkg = ROOT / "opv-cxx-demod_amd"
+    for stem in ("k_frontend", "k_frontend_x4"):
+        subprocess.run(["make", "-s", "-C", str(pkg), f"build/{stem}.al.s"], check=True, capture_output=True)
+        a = (pkg / "build" / f"{stem}.dev.s").read_text().split("\n")
+        b = (pkg / "build" / f"{stem}.al.s").read_text().split("\n")
+        assert len(a) == len(b)
+        widened = 0
+        for x, y in zip(a, b):
+            if x == y:
+                continue
+            mx, my = x.split(), y.split()
+            assert mx[1:] == my[1:], (x, y)                       # operands untouched
+            assert my[0].endswith("_e64") and my[0][:-4] == re.sub(r"_e32$", "", mx[0]), (x, y)
+            assert mx[0].startswith("v_")
+            widened += 1
+        assert widened > 100, stem
+        assert (pkg / "build" / f"{stem}.hipfb").stat().st_mtime <= (pkg / "libopv_demod_hip.so").stat().st_mtime
