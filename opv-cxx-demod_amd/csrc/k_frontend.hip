@@ -347,7 +347,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     double kc_tiny = 1e-100;
     asm volatile("" : "+v"(kc_tiny));
     double kc_halfpi = 1.57079632679489661923, kc_32 = 32.0, kc_m1_32 = -1.0 / 32.0, kc_gain = st.afc_alpha * (kSymRate / kTwoPi);
-    [[maybe_unused]] double kc_64 = 64.0, kc_m1_64 = -1.0 / 64.0, kc_magic = 6755399441055744.0 + 64.0;   // 1.5 * 2^52 + 64
+    [[maybe_unused]] double kc_64 = 128.0, kc_m1_64 = -1.0 / 128.0, kc_magic = 6755399441055744.0 + 128.0;   // rows per unit, its inverse, 1.5 * 2^52 + 128
     asm volatile("" : "+v"(kc_64), "+v"(kc_m1_64), "+v"(kc_magic));
     asm volatile("" : "+v"(kc_tfmax), "+v"(kc_beta), "+v"(kc_alpha), "+v"(kc_fomax), "+v"(kc_eps));
     asm volatile("" : "+v"(kc_halfpi), "+v"(kc_32), "+v"(kc_m1_32), "+v"(kc_gain));
@@ -932,7 +932,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
 
             // ---- 3. divides (one reciprocal for both), timing loop, AFC --------------------------------
             double ted, h = 0;
-            [[maybe_unused]] double2 c01{0, 0}, c23{0, 0}, c45{0, 0}, c67{0, 0};
+            [[maybe_unused]] double2 c01{0, 0}, c23{0, 0}, c45{0, 0};
             if constexpr (kFirst) {
                 double y = __builtin_amdgcn_rcp(den);
                 const double num = el - ee;
@@ -952,14 +952,14 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 // q = (|cy| - |cx|) / (|cy| + |cx|) in [-1, 1], good to 2^-48 without a residual step: 3.5e-15 rad on the
                 // angle, i.e. 3e-14 Hz x afc_alpha / 0.001 on fo - nothing rounds on it the way pos does on ted
                 const double ratio = dif * idm;
-                // nearest expansion point k/64, k = -64..64, by the 1.5 * 2^52 trick: the sum's low word IS the row index
-                // k + 64, and subtracting the constant gives k as a double - no v_rndne, no v_cvt
+                // nearest expansion point k/128, k = -128..128, by the 1.5 * 2^52 trick: the sum's low word IS the row index
+                // k + 128, and subtracting the constant gives k as a double - no v_rndne, no v_cvt
                 const double kt = fma(ratio, kc_64, kc_magic);
                 const double kd = kt - kc_magic;
-                h = fma(kd, kc_m1_64, ratio);                       // |h| <= 1/128
-                const unsigned char* rowb = reinterpret_cast<const unsigned char*>(atab) + ((unsigned)dlo(kt) << 6);
+                h = fma(kd, kc_m1_64, ratio);                       // |h| <= 1/256
+                const unsigned char* rowb = reinterpret_cast<const unsigned char*>(atab) + __umul24((unsigned)dlo(kt), 48u);
                 const double2* trow = reinterpret_cast<const double2*>(rowb);
-                c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
+                c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
                 ted = num * iden;
                 ted = fma(fma(-den, ted, num), iden, ted);
             }
@@ -977,9 +977,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0xC17F);                 // lgkmcnt(1): the table row landed (only the tap read may be in flight)
                 __builtin_amdgcn_sched_barrier(0);
-                pd = fma(c67.y, h, c67.x);                          // degree-7 Horner: pi/4 + atan(q)
-                pd = fma(pd, h, c45.y);
-                pd = fma(pd, h, c45.x);
+                pd = fma(c45.y, h, c45.x);                          // degree 5: pi/4 + atan(q)
                 pd = fma(pd, h, c23.y);
                 pd = fma(pd, h, c23.x);
                 pd = fma(pd, h, c01.y);
@@ -1109,18 +1107,18 @@ extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_wg4(OpvStream* 
 template <int NT>
 __device__ __forceinline__ void load_atan_table_q(unsigned char* lds_tab) {
     double* atab = reinterpret_cast<double*>(lds_tab);
-    for (int i = threadIdx.x; i < 129 * 8; i += NT) atab[i] = (&kOpvAtanTabQ[0][0])[i];
+    for (int i = threadIdx.x; i < 257 * 6; i += NT) atab[i] = (&kOpvAtanTabQ[0][0])[i];
 }
 extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_rb(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
                                                                     int n_streams) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[kTabOff + 129 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[kTabOff + 257 * 48];
     load_atan_table_q<64>(lds_all + kTabOff);
     __syncthreads();
     msk_frontend_body<1, 0, true>(streams, cfg, n_streams, lds_all);
 }
 extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_rb_wg4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
                                                                          int n_streams) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * kTabOff + 129 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * kTabOff + 257 * 48];
     load_atan_table_q<256>(lds_all + 4 * kTabOff);
     __syncthreads();
     msk_frontend_body<4, 0, true>(streams, cfg, n_streams, lds_all);

@@ -28,7 +28,7 @@
 //     with X[16];
 //   * every stream-level quantity (pos, fo, tf, previous sums, chunk bookkeeping) lives in VGPRs,
 //     replicated over the 16 lanes of its row; rows run their own chunk schedule under exec masks;
-//   * int16 IQ: a 1024-sample ring per row in LDS (+ 64-sample guard mirroring its head), refilled in
+//   * int16 IQ: a 1024-sample ring per row in LDS (+ 60-sample guard mirroring its head), refilled in
 //     256-sample blocks (one direct-to-LDS 16 B/lane load of the WHOLE wave per row and block), requested
 //     one refill point (four symbols) before their first use and awaited with one s_waitcnt vmcnt(0) there.
 //
@@ -52,7 +52,8 @@ constexpr double kDeltaPerHz = kTwoPi / kFs;    // d = 2 pi fo / Fs (ref :210-21
 
 constexpr uint32_t kRingSamples = 1024;
 constexpr uint32_t kRingBytes = kRingSamples * 4;   // 4096
-constexpr uint32_t kGuardBytes = 256;               // mirror of the ring's first 64 samples
+constexpr uint32_t kGuardBytes = 240;               // mirror of the ring's first 60 samples (a tap reaches 200 B past the ring; 240 keeps
+                                                    // two 16-stream workgroups with their 12 KB angle table inside a CU's 160 KB)
 constexpr uint32_t kRowBytes = kRingBytes + kGuardBytes;
 constexpr uint32_t kBlock = 256;                    // samples per refill block (64 lanes x 16 B: the WHOLE wave loads for one row)
 // Refill rule, applied every fourth symbol after the previous blocks have landed (g = floor(pos) of the row, hi = end of
@@ -62,7 +63,7 @@ constexpr uint32_t kBlock = 256;                    // samples per refill block 
 // overwrites samples below hi - 768 <= g - 120, which nothing reads any more. At most one block per row and refill point.
 constexpr uint32_t kAheadMin = 648;
 constexpr uint32_t kTabOff = 4 * kRowBytes;         // 17408
-// LDS per workgroup: WPB x kTabOff + the atan table (129 x 64 B) = 25 664 B for one wave (six workgroups per CU), 77 888 B for four (two)
+// LDS per workgroup: WPB x kTabOff + the atan table (257 x 48 B) = 29 680 B for one wave (five workgroups per CU), 81 712 B for four (two)
 static_assert(kTabOff % 16 == 0, "16-byte LDS alignment");
 
 typedef __attribute__((address_space(1))) double gdouble;
@@ -178,7 +179,7 @@ __device__ __noinline__ double2 silence_pd_x4(double dr, double di, double pa, d
 
 // this translation unit's own image of the angle table (opv_atan2.h: kOpvAtanTabQ): every .hip file is compiled to a
 // code object of its own (no relocatable device code), so that the two front-end files can go through tools/align_vop3.py
-__constant__ double kOpvAtanTabQx4[129][8] = {
+__constant__ double kOpvAtanTabQx4[257][6] = {
 #include "opv_atan_table_q.inc"
 };
 
@@ -192,10 +193,10 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
     const bool have = sidx < n_streams;
     OpvStream& st = streams[have ? sidx : n_streams - 1];   // idle rows read a valid record and never write
 
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[WPB * kTabOff + 129 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[WPB * kTabOff + 257 * 48];
     unsigned char* const lds = lds_all + wave * kTabOff;    // this wave's four rings
     double* atab = reinterpret_cast<double*>(lds_all + WPB * kTabOff);
-    for (int i = threadIdx.x; i < 129 * 8; i += 64 * WPB) atab[i] = (&kOpvAtanTabQx4[0][0])[i];
+    for (int i = threadIdx.x; i < 257 * 6; i += 64 * WPB) atab[i] = (&kOpvAtanTabQx4[0][0])[i];
     const unsigned char* ring = lds + (uint32_t)row * kRowBytes;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const uint32_t ring_lds = lds_base + (uint32_t)row * kRowBytes;
@@ -298,7 +299,7 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
                     const uint32_t hi_r = (uint32_t)__builtin_amdgcn_readlane((int)hi, 16 * r);
                     issue_wide(r, hi_r);
                     if (((hi_r * 4u) & (kRingBytes - 1u)) == 0u) {   // ring head: mirror its first 64 samples into the guard
-                        if (row == r) issue_block(kRingBytes);
+                        if (row == r && t < 15) issue_block(kRingBytes);   // 15 lanes x 16 B = the guard's 240 B
                     }
                 }
             }
@@ -412,11 +413,11 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
         const double ratio = dif * idm;                     // good to 2^-48: 3.5e-15 rad on the angle
         // the angle's table row is requested here and used after the timing loop: with one wave per SIMD nothing else
         // covers the LDS round trip (the row index is in range on every path: |ratio| <= 1)
-        // nearest expansion point k/64 by the 1.5 * 2^52 trick: the sum's low word is the row index k + 64
-        const double kt = fma(ratio, 64.0, 6755399441055744.0 + 64.0);
-        const double h = fma(kt - (6755399441055744.0 + 64.0), -1.0 / 64.0, ratio);   // |h| <= 1/128
-        const double2* trow = reinterpret_cast<const double2*>(atab + ((unsigned)dlo(kt) << 3));
-        const double2 c67 = trow[3], c45 = trow[2], c23 = trow[1], c01 = trow[0];
+        // nearest expansion point k/128 by the 1.5 * 2^52 trick: the sum's low word is the row index k + 128
+        const double kt = fma(ratio, 128.0, 6755399441055744.0 + 128.0);
+        const double h = fma(kt - (6755399441055744.0 + 128.0), -1.0 / 128.0, ratio);   // |h| <= 1/256
+        const double2* trow = reinterpret_cast<const double2*>(atab + (unsigned)dlo(kt) * 6u);
+        const double2 c45 = trow[2], c23 = trow[1], c01 = trow[0];
         __builtin_amdgcn_sched_barrier(0);
         double ted = num * iden;
         ted = fma(fma(-den, ted, num), iden, ted);
@@ -429,9 +430,7 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
         __builtin_amdgcn_sched_barrier(0);
         // ---- AFC (ref :289-306): not on the first symbol of a call -------------------------------
         if (!kGeneric || !first) {
-            double pd = fma(c67.y, h, c67.x);                   // degree 7: pi/4 + atan(q)
-            pd = fma(pd, h, c45.y);
-            pd = fma(pd, h, c45.x);
+            double pd = fma(c45.y, h, c45.x);                   // degree 5: pi/4 + atan(q)
             pd = fma(pd, h, c23.y);
             pd = fma(pd, h, c23.x);
             pd = fma(pd, h, c01.y);

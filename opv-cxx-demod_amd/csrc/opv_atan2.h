@@ -45,30 +45,28 @@ OPV_HD inline double opv_atan2(double y, double x) {
     return y < 0 ? -p : p;
 }
 
-// ---- the same angle without the octant fix-up (k_frontend.hip, row-broadcast mapping) ---------------------------------
-// atan(|y| / |x|) = pi/4 + atan(q), q = (|y| - |x|) / (|y| + |x|) in [-1, 1]: 129 rows of degree-7 Taylor coefficients of
-// pi/4 + atan around k/64 (|h| <= 1/128), seven FMAs, no compare / select for the octant. ABSOLUTE accuracy like
-// opv_atan2 (max abs error vs glibc < 5e-16); the relative accuracy of tiny angles is that of an angle near pi/4
-// (q near -1 cancels against the table's constant term) - the AFC integrates the angle, so the absolute error counts.
-// An argument on the positive x axis gives exactly 0 (row 0 starts with an exact 0 and h = 0).
+// ---- the same angle without the octant fix-up (k_frontend.hip's row-broadcast body, k_frontend_x4.hip) -----------------
+// atan(|y| / |x|) = pi/4 + atan(q), q = (|y| - |x|) / (|y| + |x|) in [-1, 1]: 257 rows (k/128, |h| <= 1/256) of a degree-5
+// polynomial f(0) + h g(h), g a degree-4 near-minimax fit (tools/gen_atan_table.py): five FMAs, no compare / select for
+// the octant. ABSOLUTE accuracy like opv_atan2 (max abs error vs glibc < 5e-16); the relative accuracy of tiny angles is
+// that of an angle near pi/4 (q near -1 cancels against the table's constant term) - the AFC integrates the angle, so the
+// absolute error counts. An argument on the positive x axis gives exactly 0 (row 0 starts with an exact 0 and h = 0).
 #ifdef __HIP_DEVICE_COMPILE__
 __constant__
 #else
 static const
 #endif
-double kOpvAtanTabQ[129][8] = {
+double kOpvAtanTabQ[257][6] = {
 #include "opv_atan_table_q.inc"
 };
 
 OPV_HD inline double opv_atan2_q(double y, double x) {
     const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
     const double q = (ay - ax) / (ay + ax);              // in [-1, 1]
-    const double kd = __builtin_rint(q * 64.0);          // nearest expansion point k/64
-    const double h = __builtin_fma(kd, -1.0 / 64.0, q);  // |h| <= 1/128, exact
-    const double* t = kOpvAtanTabQ[(int)kd + 64];
-    double p = t[7];
-    p = __builtin_fma(p, h, t[6]);
-    p = __builtin_fma(p, h, t[5]);
+    const double kd = __builtin_rint(q * 128.0);         // nearest expansion point k/128
+    const double h = __builtin_fma(kd, -1.0 / 128.0, q); // |h| <= 1/256, exact
+    const double* t = kOpvAtanTabQ[(int)kd + 128];
+    double p = t[5];
     p = __builtin_fma(p, h, t[4]);
     p = __builtin_fma(p, h, t[3]);
     p = __builtin_fma(p, h, t[2]);
