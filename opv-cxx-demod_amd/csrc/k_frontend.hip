@@ -37,7 +37,7 @@
 //     samples; with 15 samples per row, 2 x 15 FMACs give ALL window sums of the symbol (on-time / early / late
 //     correlations of both tones + the on-time sums P1..P4) as row partials in lane t = lane & 15, one all-reduce over
 //     the four rows completes them, v_mov_b64_dpp row_newbcast hands out what the loop filters need, the energies and
-//     the dominant-tone select are lane-parallel. 157 VALU instructions per symbol.
+//     the dominant-tone select are lane-parallel. 153 VALU instructions per symbol.
 //     Round-1 body (`symbol`, kernels k_msk_frontend / _wg4 / _dual, mapping -1 / -2): products per lane, then
 //     v_permlane32_swap / v_permlane16_swap (reduce-scatter, 2 steps) + DPP row rotations, result handed to every lane
 //     by v_readlane (no LDS scratch). The on-time gate goes first (4 values); it decides the soft value and the
@@ -815,7 +815,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         // every lane (one instruction per double instead of two v_readlane + the SGPR-operand restrictions), and the four
         // early / late energies are formed lane-parallel (square, row_ror:8, add: Re at t, Im at t + 8), the dominant
         // tone's pair selected lane-parallel (row_shl:2), before two of them are handed out. The phase detector's angle
-        // comes without the octant fix-up (opv_atan2.h: opv_atan2_q, 129-row table of pi/4 + atan, degree 7).
+        // comes without the octant fix-up (opv_atan2.h: opv_atan2_q, 257-row table of pi/4 + atan, degree 5).
         // Scheduling notes: hipcc counts an asm block as no wait state and pads the fp64 instruction behind one with an
         // s_nop; every block here is therefore followed by a 32-bit instruction that was needed anyway, and the wait
         // states DPP reads / permlane swaps need behind a VALU write are filled with useful instructions, not s_nop.

@@ -5,18 +5,18 @@
 // (opv_capi.hip: opv_set_frontend / automatic from 2049 streams).
 //
 // Why: a symbol's loop filters, divides and atan2 are scalar work per STREAM. With one stream per
-// wave they are executed on 64 lanes for one result (about 65 of that kernel's 164 instructions per
+// wave they are executed on 64 lanes for one result (about 65 of that kernel's 161 instructions per
 // symbol). Here a wave instruction advances four streams: the scalar tail is shared by four, the
 // reductions stay inside a DPP row (4 rotations, no cross-row swaps), and the per-sample work grows only
 // from one to four taps per lane. Rows reach their chunk ends, first symbols and refill points at different
 // symbols, so the loop carries per-row call state under exec masks; symbols run in BATCHES that provably need none
 // of it for any row (round 2: the same statements compiled without the tests), the rings are refilled in 256-sample
-// blocks by the whole wave, the row sums run four in lockstep and finish with broadcast FMACs; together they took the per-wave-symbol count (rocprofv3 PMC, MI355X, 4096 streams) from
-// 448 VALU + 87 SALU + 12 LDS/VMEM to 321 + 25 + 8 = 89 issued instructions per symbol and stream (one wave per stream:
-// 164). Because a wave carries four streams the chip fills four times later, and a launch lasts as long as one wave
-// needs for its four streams: 47.5 ms for 30 frames whether the context has 1025 or 4096 streams (four waves per
+// blocks by the whole wave, the row sums run four in lockstep and finish with broadcast FMACs; together they took the
+// per-wave-symbol count (rocprofv3 PMC, MI355X, 4096 streams) from 448 VALU + 87 SALU + 12 LDS/VMEM to 319 + 25 + 7 =
+// 88 issued instructions per symbol and stream (one wave per stream: 161). Because a wave carries four streams the chip fills four times later, and a launch lasts as long as one wave
+// needs for its four streams: 47 ms for 30 frames whether the context has 1025 or 4096 streams (four waves per
 // workgroup = one per SIMD of a CU by construction, see msk_frontend_x4_body), 81 ms for 8192 (two waves per SIMD):
-// front-end alone 225 GS/s at 4096 streams, 265 at 8192 (round 1: 87 / 130). The one-wave kernel runs 1024 streams at a
+// front-end alone 228 GS/s at 4096 streams, 264 at 8192 (round 1: 87 / 130). The one-wave kernel runs 1024 streams at a
 // time in 23 ms per 30 frames: faster up to 2048 streams, slower from 2049 on, which is where the shim switches
 // (DESIGN.md §3.1).
 //
