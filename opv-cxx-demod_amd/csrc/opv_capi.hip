@@ -468,7 +468,7 @@ extern "C" int opv_process(opv_ctx* c) {
     } else if (x4 && S <= kFrontendX4Wg4MaxStreams)        // up to two waves per SIMD: four waves (16 streams) per workgroup
         k_msk_frontend_x4_wg4<<<(S + 15) / 16, 256, 0, c->stream>>>(c->d_streams, g, S);
     else if (x4) k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
-    // one wave per stream, row-broadcast reduction (k_frontend.hip: symbol_r). Its 281 registers allow one wave per SIMD;
+    // one wave per stream, row-broadcast reduction (k_frontend.hip: symbol_r). Its 272-278 registers allow one wave per SIMD;
     // four waves per workgroup (one per SIMD of a CU by construction) as soon as single-wave workgroups could double up
     else if (S > kFrontendWg4MinStreams) k_msk_frontend_rb_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);
     else k_msk_frontend_rb<<<S, 64, 0, c->stream>>>(c->d_streams, g, S);
