@@ -52,19 +52,30 @@ def load_pkg(name):
 
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` from a bare shell: start the N ranks as child processes (this parent never
-    touches a GPU, and nothing is exec'ed from a process that has), wait, exit with the worst status."""
+    touches a GPU, and nothing is exec'ed from a process that has), watch them, exit with the worst status. A rank
+    that fails takes the others with it: they would otherwise sit in the rendezvous until its timeout."""
     import socket
-    with socket.socket() as sk:
+    with socket.socket() as sk:                        # a free port now; rank 0's store binds it a moment later
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    me = [sys.executable, str(Path(__file__).resolve())] + argv
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OPV_BENCH_SPAWNED="1")
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(me, env=env))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        for p in list(live):
+            if p.poll() is None:
+                continue
+            live.remove(p)
+            if p.returncode != 0 and rc == 0:
+                rc = abs(p.returncode)
+                for q in live:                         # fresh children this parent started itself: safe to end
+                    q.terminate()
+        time.sleep(0.05)
     sys.exit(rc)
 
 

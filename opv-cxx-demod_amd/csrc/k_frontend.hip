@@ -87,10 +87,12 @@ constexpr uint32_t kBack = 11;                  // lowest tap is floor(pos) - 10
 constexpr uint32_t kAhead = 56;                 // highest tap is floor(pos) + 54, one spare
 static_assert((kRing & (kRing - 1)) == 0, "ring must be a power of two");
 
-// LDS map (bytes): ring | guard | atan table (33 rows x 10 doubles: c0..c8, pad)
+// LDS map (bytes): WPB x (ring | guard), then ONE atan table shared by the workgroup's waves:
+//   row-broadcast body (k_msk_frontend_rb / _rb_wg4): 257 rows x 6 doubles (opv_atan_table_q.inc: pi/4 + atan(q) at q = k/128,
+//     degree-5 remainder) = 12 336 B -> 28 736 B for one wave, 77 936 B for four;
+//   round-1 body (k_msk_frontend / _wg4 / _dual): 33 rows x kTabRow doubles (c0..c8, pad) = 2 640 B -> 19 040 B / 68 240 B
 constexpr uint32_t kTabOff = kRingBytes + kGuardBytes;   // 16400
 constexpr uint32_t kTabRow = 10;
-// LDS per workgroup: WPB x kTabOff + the atan table = 19 040 B for one wave (eight workgroups per CU), 68 240 B for four (two)
 static_assert(kTabOff % 16 == 0, "16-byte LDS alignment");
 
 typedef __attribute__((address_space(1))) double gdouble;

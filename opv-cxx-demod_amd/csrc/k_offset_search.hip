@@ -204,7 +204,7 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
         return e;
     };
     // Decide among candidates [c0, c1) the way the reference's loop does (strict '>' against the running best),
-    // after re-evaluating in its own order every candidate that is within 1e-9 of the best energy in play
+    // after re-evaluating in its own order every candidate that is within kTieRel (1e-11) of the best energy in play
     // (the running best included) unless the winner is clear.
     auto decide = [&](int c0, int c1, double base_offset, double step, bool fine) {
         if (tid >= c0 && tid < c1) s_e[tid] = poly_energy(base_offset + step * (double)(tid - c0));
@@ -237,6 +237,9 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
         if (tid == 0) {
             for (int c = c0; c < c1; ++c) {
                 st.energies[c] = s_e[c];
+                // the fine candidate at the coarse winner's own offset: a bit-identical repeat in the reference, never
+                // '>' there - here its polynomial value may not be compared with a re-evaluated (exact) best
+                if (fine && base_offset + step * (double)(c - c0) == s_best) continue;
                 if (s_e[c] > s_best_e) {                  // strict: first maximum wins (ref :161, :195)
                     s_best_e = s_e[c];
                     if (fine) s_fine = base_offset + step * (double)(c - c0);

@@ -135,6 +135,9 @@ struct opv_ctx {
     uint64_t cap_soft = 0;
     uint32_t cap_frames = 0, cap_events = 0, cap_chunks = 0;
     bool mirror_valid = false;
+    // Back-pressure: a stream that paused in the last round (OpvStream.stalled) must be retried by the next
+    // opv_process even if the caller pushed nothing new. Unknown (= true) from a launch until the next refresh().
+    bool maybe_stalled = false;
     // device modulator cache: NCO phases at symbol starts (data-independent, grown on demand)
     std::vector<double> tx_phases;       // host copy, 2 doubles per symbol
     double tx_ph1 = 0.0, tx_ph2 = 0.0;   // phases after the last cached symbol
@@ -162,6 +165,8 @@ struct opv_ctx {
         HIPCHK(hipMemcpy(mirror.data(), d_streams, sizeof(OpvStream) * n_streams, hipMemcpyDeviceToHost));
         mirror_valid = true;
         ++mirror_epoch;
+        maybe_stalled = false;
+        for (const OpvStream& m : mirror) maybe_stalled |= m.stalled != 0;
         return OPV_OK;
     }
     size_t pool_bytes() const {
@@ -441,8 +446,11 @@ extern "C" int opv_process(opv_ctx* c) {
         h.last_round_avail = h.n_avail;
         h.dirty = false;
     }
-    if (!any) return OPV_OK;
+    // nothing new: still run the round while a stream may be waiting behind back-pressure (it resumes by itself once
+    // the tracker has consumed soft symbols / the caller has popped frames; the cursors travel with every round)
+    if (!any && !c->maybe_stalled) return OPV_OK;
     c->mirror_valid = false;
+    c->maybe_stalled = true;
     // pinned -> device, in stream order behind the previous round's kernels; no host wait
     HIPCHK(hipMemcpyAsync(c->d_in, in, sizeof(StreamIn) * S, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->in_ev[slot], c->stream));
@@ -606,7 +614,6 @@ extern "C" long opv_pop_frames(opv_ctx* c, int s, uint8_t* out, size_t cap, opv_
         }
         if (stop) break;
     }
-    if (f != h.popped && st.stalled) h.dirty = true;  // room again: the next opv_process resumes the stream
     h.popped = f;
     return (long)w;
 }

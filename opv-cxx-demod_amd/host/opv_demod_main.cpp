@@ -1,7 +1,7 @@
 // opv_demod_main.cpp — host program with the process contract of the reference `opv-demod`
 // (reference src/opv-demod.cpp:943-1217): int16 I/Q on stdin, 134-byte frames on stdout
-// (-r), human text on stderr, flags -q -r -s -a -o -h (-c/-p: coherent mode, out of scope),
-// exit status 0 iff at least one frame decoded. All arithmetic runs on the MI355X through
+// (-r), human text on stderr, flags -q -r -s -c -a -o -p -h (-c/-p: the batch Costas-loop demodulator,
+// csrc/k_coherent.hip - prefix parity only), exit status 0 iff at least one frame decoded. All arithmetic runs on the MI355X through
 // the C ABI in include/opv_demod.h; this file only moves bytes and prints.
 #include <unistd.h>
 
@@ -213,6 +213,25 @@ int die(const char* what) {
     return 2;
 }
 
+// After the last opv_process: a stream held back by back-pressure (opv_stream_state.stalled - unpopped frames or
+// unread soft symbols fill a ring) has not finished. Keep draining and processing until it has; a round that
+// neither pops anything nor advances the stream is an error, never a silent truncation.
+int finish(opv_ctx* ctx, Sink& sink) {
+    for (;;) {
+        opv_stream_state st;
+        if (opv_get_state(ctx, 0, &st) < 0) return -1;
+        if (!st.stalled) return 0;
+        const uint64_t sym0 = st.total_symbols;
+        const int rel0 = st.frames_released, dec0 = sink.decoded;
+        if (opv_process(ctx) < 0 || sink.drain() < 0) return -1;
+        if (opv_get_state(ctx, 0, &st) < 0) return -1;
+        if (st.stalled && st.total_symbols == sym0 && st.frames_released == rel0 && sink.decoded == dec0) {
+            fprintf(stderr, "opv-demod: stream stalled (0x%x) without progress: device rings too small for this input\n", st.stalled);
+            return -2;
+        }
+    }
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -307,6 +326,7 @@ int main(int argc, char** argv) {
         }
         if (opv_flush(ctx, 0) < 0 || opv_process(ctx) < 0) return die("opv_flush");
         if (sink.drain() < 0) return die("drain");
+        if (finish(ctx, sink) < 0) return die("finish");
         opv_stream_state st;
         opv_get_state(ctx, 0, &st);
         if (!o.quiet) {  // ref :1115-1122
@@ -340,6 +360,8 @@ int main(int argc, char** argv) {
     }
     Sink sink{ctx, o};
     if (sink.drain() < 0) return die("drain");
+    if (finish(ctx, sink) < 0) return die("finish");
+    if (opv_get_state(ctx, 0, &st) < 0) return die("opv_get_state");
     if (!o.quiet) {  // ref :1208-1214
         fprintf(stderr, "════════════════════════════════════════════════════════════════════\n");
         fprintf(stderr, "Summary: %d frames (%d perfect, %d errors)\n", sink.decoded, sink.perfect, sink.decoded - sink.perfect);

@@ -171,6 +171,26 @@ int main(int argc, char** argv) {
         if (any && drain() < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
     }
     if (drain() < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
+    // streams held back by back-pressure (opv_stream_state.stalled) have not finished: keep going until none is, and
+    // fail loudly if a round moves nothing
+    auto progress = [&](bool* stalled) -> uint64_t {
+        uint64_t p = 0;
+        *stalled = false;
+        for (int k = 0; k < S; ++k) {
+            opv_stream_state st;
+            if (opv_get_state(ctx, k, &st) < 0) continue;
+            *stalled |= st.stalled != 0;
+            p += st.total_symbols + (uint64_t)st.frames_released + (uint64_t)in[k].frames;
+        }
+        return p;
+    };
+    for (;;) {
+        bool stalled = false;
+        const uint64_t p0 = progress(&stalled);
+        if (!stalled) break;
+        if (drain() < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
+        if (progress(&stalled) == p0 && stalled) { fprintf(stderr, "opv-rx-bridge: a stream stalled without progress\n"); return 2; }
+    }
     long total = 0;
     for (int k = 0; k < S; ++k) {
         total += in[k].frames;

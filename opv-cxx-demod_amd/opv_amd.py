@@ -315,9 +315,18 @@ class Demod:
         res = []
         for s in range(self.n_streams):
             fr, meta = self.pop_frames(s)
+            ev = self.pop_events(s)
             st = self.state(s)
-            res.append(dict(frames=fr, meta=meta, events=self.pop_events(s), soft=self.soft(s), state=st,
-                            chunks=self.chunks(s)))
+            while st.stalled:                   # back-pressure: pop, run another round, until the stream has finished
+                before = (st.total_symbols, st.frames_released, len(fr))
+                self.process()
+                f2, m2 = self.pop_frames(s)
+                fr, meta = np.concatenate([fr, f2]), np.concatenate([meta, m2])
+                ev = np.concatenate([ev, self.pop_events(s)])
+                st = self.state(s)
+                if st.stalled and (st.total_symbols, st.frames_released, len(fr)) == before:
+                    raise OpvError(f"stream {s} stalled (0x{st.stalled:x}) without progress")
+            res.append(dict(frames=fr, meta=meta, events=ev, soft=self.soft(s), state=st, chunks=self.chunks(s)))
         return res
 
 

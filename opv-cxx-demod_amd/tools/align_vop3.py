@@ -20,8 +20,11 @@ import sys
 import tempfile
 from pathlib import Path
 
-LLVM = Path("/opt/rocm/lib/llvm/bin")
-TARGET = ["-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950"]
+import os
+
+# tool chain and target come from the Makefile (LLVMBIN / ARCH in the environment), not from this file
+LLVM = Path(os.environ.get("LLVMBIN", "/opt/rocm/lib/llvm/bin"))
+TARGET = ["-target", "amdgcn-amd-amdhsa", "-mcpu=" + os.environ.get("ARCH", "gfx950")]
 
 
 def assemble(src, obj):
@@ -38,9 +41,9 @@ def disassemble(obj):
         if m:
             cur = funcs.setdefault(m.group(1), [])
             continue
-        m = re.match(r"^\s+(\S+).*//\s*([0-9A-F]+):", line)
+        m = re.match(r"^\s+(\S+)(.*?)//\s*([0-9A-F]+):", line)
         if m and cur is not None:
-            cur.append([int(m.group(2), 16), 0, m.group(1)])
+            cur.append([int(m.group(3), 16), 0, m.group(1), " ".join(m.group(2).split())])
     for ins in funcs.values():
         for a, b in zip(ins, ins[1:]):
             a[1] = b[0] - a[0]
@@ -147,6 +150,26 @@ def plan(ins, lines_idx, lines, banned):
     return flips
 
 
+def signature(x):
+    """what must survive the pass: the operation and its operands (branch targets are addresses: they move)"""
+    mn = base(x[2])
+    return (mn, "" if mn.startswith(("s_branch", "s_cbranch", "s_call")) else x[3])
+
+
+def verify(before, after, flipped):
+    """exit non-zero unless every function the pass touched still holds the same instruction and operand sequence"""
+    for f in flipped:
+        a, b = [signature(x) for x in before[f]], [signature(x) for x in after.get(f, [])]
+        while a and a[-1][0] == "s_nop":       # padding behind s_endpgm up to the next function is not code
+            a.pop()
+        while b and b[-1][0] == "s_nop":
+            b.pop()
+        if a != b:
+            k = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+            sys.exit(f"align_vop3: {f}: re-assembled code differs from the input at instruction {k}: "
+                     f"{a[k] if k < len(a) else None} vs {b[k] if k < len(b) else None}")
+
+
 def stats(ins):
     eight = [x for x in ins if x[1] == 8]
     return len(eight), sum(1 for x in eight if x[0] % 8 == 4)
@@ -169,6 +192,8 @@ def main():
             for f, ins in before.items():
                 idx = where.get(f)
                 if idx is None or len(idx) > len(ins) or not same_instructions(ins, idx, lines):
+                    if attempt == 0 and len(ins) > 200:
+                        print(f"align_vop3: WARNING: {f} ({len(ins)} instructions) does not match its text 1:1 and is left unaligned", file=sys.stderr)
                     continue                    # not a function of this file's text (or no 1:1 match): left untouched
                 ins = ins[:len(idx)]            # (behind s_endpgm the object carries padding up to the next function)
                 fl = plan(ins, idx, lines, banned[f])
@@ -190,6 +215,7 @@ def main():
         else:
             sys.exit("align_vop3: no assembling output after 40 attempts")
         after = disassemble(obj)
+        verify(before, after, flipped)
         dst.write_text("\n".join(out))
         for f in before:
             if f in flipped:

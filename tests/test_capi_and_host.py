@@ -150,3 +150,20 @@ def test_alignment_pass_changes_encodings_only(amd):
             widened += 1
         assert widened > 100, stem
         assert (pkg / "build" / f"{stem}.hipfb").stat().st_mtime <= (pkg / "libopv_demod_hip.so").stat().st_mtime
+
+
+def test_alignment_pass_verifies_its_own_output():
+    """the pass compares the re-assembled object with the input instruction by instruction (operation + operands,
+    modulo _e32 / _e64 and branch targets) and refuses to write an output that differs"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("align_vop3", ROOT / "opv-cxx-demod_amd" / "tools" / "align_vop3.py")
+    al = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(al)
+    before = {"k": [[0, 4, "v_add_f32_e32", "v0, v1, v2"], [4, 8, "v_fma_f64", "v[0:1], v[2:3], v[4:5], v[6:7]"],
+                    [12, 4, "s_cbranch_scc1", "65531"], [16, 4, "s_endpgm", ""], [20, 4, "s_nop", "0"]]}
+    same = {"k": [[0, 8, "v_add_f32_e64", "v0, v1, v2"], [8, 8, "v_fma_f64", "v[0:1], v[2:3], v[4:5], v[6:7]"],
+                  [16, 4, "s_cbranch_scc1", "65530"], [20, 4, "s_endpgm", ""]]}
+    al.verify(before, same, {"k": [0]})
+    for bad in ([[0, 8, "v_add_f32_e64", "v0, v1, v3"]] + same["k"][1:], [[0, 8, "v_sub_f32_e64", "v0, v1, v2"]] + same["k"][1:], same["k"][:-1]):
+        with pytest.raises(SystemExit):
+            al.verify(before, {"k": bad}, {"k": [0]})

@@ -99,7 +99,7 @@ def test_512_stream_context_vs_oracle():
     import torch
     from __graft_entry__ import load_opv_amd, load_pkg_module
     from oracle_lib import Oracle
-    from test_gpu_parity import events_match
+    from test_gpu_parity import events_match, no_ties
     amd, workload = load_opv_amd(), load_pkg_module("workload")
     dev = torch.device("cuda", 0)
     S, F = 512, 3
@@ -120,6 +120,7 @@ def test_512_stream_context_vs_oracle():
         assert np.array_equal(meta["viterbi_metric"], e["metrics"]) and np.array_equal(meta["release_symbol"], e["frame_sym"]), k
         events_match(amd, dm.pop_events(k), e["events"])
         assert dm.state(k).est_offset_hz == e["est_offset"], k
+        no_ties(dm.state(k), f"stream {k} of 512")
         total += len(fr)
     assert total >= S * (F - 1)
     dm.close()
@@ -156,4 +157,5 @@ def test_many_stream_contexts_on_the_automatic_mapping(S):
         assert np.array_equal(meta["viterbi_metric"], e["metrics"]) and np.array_equal(meta["release_symbol"], e["frame_sym"]), k
         st = dm.state(k)
         assert st.est_offset_hz == e["est_offset"] and st.total_symbols == e["n_soft"], k
+        assert st.edge_ties == 0 and st.offset_ties == 0, k
     dm.close()
