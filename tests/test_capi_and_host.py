@@ -122,7 +122,7 @@ def test_bench_starts_its_own_ranks_and_fails_loudly_without_gpus():
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 2, p.stderr
-    assert p.stderr.count("no GPU visible") == 2, p.stderr
+    assert 1 <= p.stderr.count("no GPU visible") <= 2, p.stderr     # (the first rank to fail ends the other one)
     env["WORLD_SIZE"] = "4"
     p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=120)
     assert p.returncode == 2 and "disagrees with WORLD_SIZE=4" in p.stderr
