@@ -243,6 +243,20 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     step(check=True)                                      # untimed: the timed configuration decodes correctly
+    fe_kernel = dm.frontend_kernel()                      # what opv_process actually launched for this stream count
+    # the two input classes the product reports instead of reproducing (include/opv_demod.h: edge_ties, offset_ties)
+    states = [dm.state(k) for k in range(S)]
+    stats["edge_ties"] = int(sum(st.edge_ties for st in states))
+    stats["offset_ties"] = int(sum(st.offset_ties for st in states))
+    # live issue view of the dominant kernel: every wave times itself (s_memtime / s_memrealtime, opv_tap_wave_info)
+    wi = [dm.wave_info(k) for k in range(S)]
+    cyc = np.array([w[2] for w in wi], np.float64)
+    tick = np.array([w[3] for w in wi], np.float64)
+    syms = np.array([st.total_symbols for st in states], np.float64)
+    per_wave = 4.0 if "_x4" in fe_kernel else 1.0         # streams sharing a wave (k_frontend_x4.hip)
+    live_cps = float(np.median(cyc / np.maximum(syms * per_wave, 1.0))) if cyc.min() > 0 else None
+    live_clock = float(np.median(cyc / np.maximum(tick, 1.0)) * 100e6) if tick.min() > 0 else None
+    collective = None
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -250,6 +264,11 @@ def main():
         if rank == 0:
             g = gathered["frames"]                       # [world, S, fcap, 134] in global stream order
             assert bool((g[0] == frames_view).all().item()), "gathered frames of rank 0 differ from the local ones"
+            stats["gathered_equals_local_view"] = True
+            collective = {"backend": dist.get_backend(), "world": world, "gathered_shape": list(g.shape),
+                          "bytes_per_rank": int(frames_view.numel() + 4 * counts_view.numel()),
+                          "op": "one dist.gather of the [S, cap, 134] frame buffer + one of the [S] counts per step "
+                                "(zero-copy views of library memory), MAX all-reduce of the step time"}
             assert bool((gathered["counts"] == F).all().item()), "a gathered stream released a wrong number of frames"
             exp_all = np.stack([np.stack([workload.tx_frames(amd, gk, F) for gk in sharding.stream_range(r, world, world * S)])
                                 for r in range(world)])
@@ -264,32 +283,58 @@ def main():
     launch_samples = float(S) * n
     achieved = launch_samples * ALGO_BYTES_PER_SAMPLE / (fe_ms * 1e-3) / 1e9
 
-    # HBM bytes of the dominant kernel come from separate rocprofv3 --pmc passes (bench.py cannot
-    # profile itself); they are only attached when this run is the profiled configuration.
+    # HBM bytes and instruction counts of the dominant kernel come from separate rocprofv3 --pmc passes (bench.py
+    # cannot profile itself); they are attached only when the stored profile is of THIS kernel and configuration.
+    # Cycles per symbol and the clock are measured live in every run (above); a stored profile whose cycles differ
+    # from the live ones by more than 3 % is flagged as stale.
+    n_sym = float(syms.sum())
     traffic = None
-    traffic_note = "no PMC passes recorded for this configuration (see profiles/collect.sh)"
-    issue = None
+    traffic_note = "no PMC passes recorded for this kernel / configuration (see profiles/collect.sh)"
+    issue = {"wave_cycles_per_symbol": round(live_cps, 1) if live_cps else None,
+             "clock_GHz": round(live_clock / 1e9, 3) if live_clock else None,
+             "source": "live: s_memtime / s_memrealtime of every wave (opv_tap_wave_info), median over the streams"}
+    n_simd = 1024
+    waves = int(np.ceil(S / per_wave))
     try:
         tj = json.loads(sorted((ROOT / "profiles").glob("r[0-9][0-9]_traffic.json"))[-1].read_text())
         w = tj["workload"]
-        if (w["streams_per_gpu"], w["frames_per_stream"], w["ebn0"]) == (S, F, args.ebn0):
+        if tj.get("kernel") == fe_kernel and (w["streams_per_gpu"], w["frames_per_stream"], w["ebn0"]) == (S, F, args.ebn0):
             traffic = round(tj["hbm_bytes_per_launch"] / (fe_ms * 1e-3) / 1e9, 3)
             traffic_note = tj["source"] + "; " + tj["correction"]
-        # The view that actually bounds this kernel: wave-instructions issued vs the issue slots of
-        # the chip (1024 SIMDs, one fp64 wave-instruction per 4 cycles each, at the 2.4 GHz the kernel holds -
-        # opv_tap_wave_info). instr_per_symbol comes from the SQ_INSTS_* passes of the same workload.
-        ips = tj.get("instr_per_symbol")
-        if ips:
-            per_sym = float(sum(ips.values()))
-            n_sym = launch_samples / 40.0
-            slots = 1024 * (fe_ms * 1e-3) * 2.4e9 / 4.0
-            issue = {"instr_per_symbol": ips, "wave_cycles_per_symbol": tj.get("wave_cycles_per_symbol"),
-                     "chip_issue_frac": round(per_sym * n_sym / slots, 4),
-                     "wave_issue_frac": round(per_sym * 4.0 / tj["wave_cycles_per_symbol"], 3) if tj.get("wave_cycles_per_symbol") else None,
-                     "note": "chip_issue_frac: issued wave-instructions / (1024 SIMDs x kernel cycles / 4); "
-                             "wave_issue_frac: the same for the SIMDs that carry a stream (one wave each)"}
+            ips = tj.get("instr_per_symbol")
+            if ips:
+                per_sym = float(sum(ips.values()))
+                issue["instr_per_symbol"] = ips
+                issue["instr_source"] = "rocprofv3 SQ_INSTS_* pass of the same kernel and workload (" + tj["source"].split(";")[0] + ")"
+                stored = tj.get("wave_cycles_per_symbol")
+                if stored and live_cps:
+                    issue["profile_wave_cycles_per_symbol"] = stored
+                    issue["profile_stale"] = bool(abs(stored - live_cps) > 0.03 * live_cps)
+                if live_cps:
+                    # a wave-instruction occupies its SIMD's issue port for 4 cycles (MI355X_MICROARCH.md, 'vector-instruction
+                    # ISSUE cost', one wave per SIMD): the fraction of its own SIMD's slots a stream's wave fills ...
+                    issue["wave_issue_frac"] = round(per_sym * per_wave * 4.0 / (live_cps * per_wave), 3)
+                    # ... and the same over the whole chip for the duration of the kernel
+                    slots = n_simd * (fe_ms * 1e-3) * (live_clock or 2.4e9) / 4.0
+                    issue["chip_issue_frac"] = round(per_sym * n_sym / slots, 4)
     except Exception:
         pass
+    issue["waves"] = waves
+    issue["simds"] = n_simd
+    issue["note"] = ("wave_issue_frac: issued wave-instructions x 4 cycles / the wave's own cycles; chip_issue_frac: issued "
+                     "wave-instructions / (1024 SIMDs x kernel cycles / 4)")
+    # fp64 vector view: the REFERENCE formulation's arithmetic, ~150 flop per sample (2 sincos + 3 complex
+    # lerps + 6 complex MACs), at the rate this kernel demodulates, against the fp64 vector peak (AMD spec 78.6 TFLOP/s =
+    # half the fp32 vector peak of MI355X_MICROARCH.md). The kernel itself issues far fewer (no sincos, 60 lerps for 120).
+    FP64_PEAK_TF, ALGO_FLOP_PER_SAMPLE = 78.6, 150.0
+    fp64_tf = launch_samples * ALGO_FLOP_PER_SAMPLE / (fe_ms * 1e-3) / 1e12
+    fp64_view = {"bound": "fp64-valu", "algorithmic_flop_per_sample": ALGO_FLOP_PER_SAMPLE, "achieved": round(fp64_tf, 3),
+                 "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": round(fp64_tf / FP64_PEAK_TF, 5)}
+    if waves <= n_simd:
+        regime = (f"issue/latency-bound per-symbol feedback recurrence: {waves} waves on {n_simd} SIMDs "
+                  f"({100.0 * waves / n_simd:.1f} % of the chip's issue ports can be used at all), not bandwidth (DESIGN.md §3.1)")
+    else:
+        regime = f"{waves} waves on {n_simd} SIMDs: every SIMD carries a stream wave, the kernel is at the chip's issue capacity"
 
     out = {
         "metric": "IQ Msamples/s demod+Viterbi (×real-time @2.168MSPS); BER vs ref",
@@ -297,23 +342,26 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"configs[3]: {S} concurrent IQ streams/GPU x {F} frames, -s semantics, "
+        "config": {"workload": (f"configs[3]: " if (S, F) == (64, 1000) else f"configs[3] shape at --streams {S} --frames {F}: ") +
+                               f"{S} concurrent IQ streams/GPU x {F} frames, -s semantics, "
                                f"amp 2000, f0 -1500..+1500 Hz, Eb/N0 {args.ebn0:g} dB" +
                                (f"; x{world} GPUs = configs[4] shape, RCCL gather of frames to rank 0" if world > 1 else ""),
                    "streams_per_gpu": S, "frames_per_stream": F, "samples_per_stream": n,
                    "parallelism": f"streams sharded {S}/GPU, no data-path collective"},
         "frames_checked": f"rank0: {stats.get('frames_exact')}/{stats.get('frames_total')} decoded frames equal the "
                           f"transmitted bytes (rest = channel errors at {args.ebn0:g} dB); GPU==reference parity is tests/",
-        "roofline": {"bound": "hbm", "kernel": "k_msk_frontend_rb", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": fe_kernel, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "traffic_note": traffic_note,
                      "issue": issue,
+                     "fp64_valu": fp64_view,
                      "kernel_ms": round(fe_ms, 3),
-                     "note": "issue/latency-bound per-symbol feedback recurrence at 64 waves per GPU, not bandwidth "
-                             "(DESIGN.md); extras.stream_sweep shows the same kernel with the chip filled"},
+                     "note": regime + "; extras.stream_sweep shows the front-end with the chip filled"},
         "kernel_ms": {k: round(float(np.mean([x[k] for x in kt])), 3) for k in kt[0]},
         "check": stats,
     }
+    if collective:
+        out["collective"] = collective
     # what a timed step spends outside the four kernels: opv_reset_stream (two stream syncs, a 90 KB upload, a
     # metrics fill), 64 opv_attach calls, the launches, and the frame gather when N > 1
     out["non_kernel_ms_per_step"] = round(out["ms_per_step"] - sum(out["kernel_ms"].values()), 3)

@@ -157,6 +157,9 @@ int opv_sync(opv_ctx* ctx);
  * per stream, one per feedback loop (exact, 6 % slower than -1). Results do not depend on the mapping beyond the
  * fp64 re-association level of the soft symbols (all decisions identical; the tests run every mapping). */
 int opv_set_frontend(opv_ctx* ctx, int streams_per_wave);
+/* Name of the front-end kernel the LAST opv_process launched ("k_msk_frontend_rb", "..._rb_wg4", "k_msk_frontend_x4_wg4", ...;
+ * "" before the first round): what a profile or a bench line should be read against. No counterpart in the reference. */
+const char* opv_frontend_kernel(opv_ctx* ctx);
 /* Restores a stream (stream = -1: every stream) to its freshly-created state (keeps buffers). */
 int opv_reset_stream(opv_ctx* ctx, int stream);
 
@@ -198,8 +201,8 @@ long opv_tap_chunks(opv_ctx* ctx, int stream, uint32_t first_chunk, double* out5
 /* 134 candidate energies of the offset search in scan order (121 coarse, 13 fine) */
 int opv_tap_offset_energies(opv_ctx* ctx, int stream, double* out134);
 
-/* Where and how fast the wavefront that served `stream` ran in the LAST front-end launch (one wave per stream
- * mapping only): out[0] = HW_REG_HW_ID, out[1] = HW_REG_XCC_ID, out[2] = shader-clock cycles (s_memtime) and
+/* Where and how fast the wavefront that served `stream` ran in the LAST front-end launch (with four streams per
+ * wave, the four share these numbers): out[0] = HW_REG_HW_ID, out[1] = HW_REG_XCC_ID, out[2] = shader-clock cycles (s_memtime) and
  * out[3] = 100 MHz ticks (s_memrealtime) spent inside the kernel. Diagnostic: placement census and the clock the
  * chip held (cycles / ticks x 100 MHz); no counterpart in the reference. */
 int opv_tap_wave_info(opv_ctx* ctx, int stream, uint64_t out[4]);

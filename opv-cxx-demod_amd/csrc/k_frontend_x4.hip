@@ -192,6 +192,7 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
     const int sidx = ((int)blockIdx.x * WPB + wave) * 4 + row;
     const bool have = sidx < n_streams;
     OpvStream& st = streams[have ? sidx : n_streams - 1];   // idle rows read a valid record and never write
+    const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[WPB * kTabOff + 257 * 48];
     unsigned char* const lds = lds_all + wave * kTabOff;    // this wave's four rings
@@ -556,6 +557,13 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
         st.origin = origin; st.n_soft = n_soft; st.total_samples = total_samples;
         st.n_chunks = n_chunks; st.tail_done = tail_done; st.overflow = overflow;
         st.stalled = stalled; st.edge_ties = edge_ties;
+        // where and at which clock the wave that carried this stream (and three others) ran (opv_tap_wave_info)
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        st.dbg_hw_id = hw; st.dbg_xcc_id = xcc;
+        st.dbg_cycles = __builtin_amdgcn_s_memtime() - dbg_t0;
+        st.dbg_ticks = __builtin_amdgcn_s_memrealtime() - dbg_r0;
     }
 }
 

@@ -143,6 +143,7 @@ struct opv_ctx {
     double tx_ph1 = 0.0, tx_ph2 = 0.0;   // phases after the last cached symbol
     double* d_tx_phases = nullptr;
     size_t d_tx_phases_cap = 0;          // symbols
+    const char* last_frontend = "";   // kernel the last opv_process launched for the front-end (opv_frontend_kernel)
     int frontend = 0;  // 0: by stream count, 1: one wave per stream, 4: four streams per wave, -1 / -2: see opv_set_frontend
     bool timing = false;
     bool timing_valid = false;
@@ -467,19 +468,30 @@ extern "C" int opv_process(opv_ctx* c) {
     const bool x4 = c->frontend == 4 || (c->frontend == 0 && S >= kFrontendX4MinStreams);
     if (c->cfg.coherent && !c->cfg.streaming) {           // -c, batch only (ref :1144-1161)
         const double wn = c->cfg.pll_bw_hz * 2.0 * M_PI, zeta = 0.707, fsym = 2168000.0 / 40.0;   // set_pll_bandwidth (ref :551-558)
+        c->last_frontend = "k_coherent_frontend";
         k_coherent_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, 2.0 * zeta * wn / fsym, wn * wn / (fsym * fsym));
     } else if (c->frontend == -2) {                        // two waves per stream (opv_set_frontend(-2))
+        c->last_frontend = "k_msk_frontend_dual";
         k_msk_frontend_dual<<<S, 128, 0, c->stream>>>(c->d_streams, g, S);
     } else if (c->frontend == -1) {                        // one wave per stream, product + swap reductions (the round-1 body)
-        if (S > kFrontendWg4MinStreams) k_msk_frontend_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);
-        else k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g, S);
-    } else if (x4 && S <= kFrontendX4Wg4MaxStreams)        // up to two waves per SIMD: four waves (16 streams) per workgroup
+        if (S > kFrontendWg4MinStreams) { c->last_frontend = "k_msk_frontend_wg4"; k_msk_frontend_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S); }
+        else { c->last_frontend = "k_msk_frontend"; k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g, S); }
+    } else if (x4 && S <= kFrontendX4Wg4MaxStreams) {      // up to two waves per SIMD: four waves (16 streams) per workgroup
+        c->last_frontend = "k_msk_frontend_x4_wg4";
         k_msk_frontend_x4_wg4<<<(S + 15) / 16, 256, 0, c->stream>>>(c->d_streams, g, S);
-    else if (x4) k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
+    } else if (x4) {
+        c->last_frontend = "k_msk_frontend_x4";
+        k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
+    }
     // one wave per stream, row-broadcast reduction (k_frontend.hip: symbol_r). Its 272-278 registers allow one wave per SIMD;
     // four waves per workgroup (one per SIMD of a CU by construction) as soon as single-wave workgroups could double up
-    else if (S > kFrontendWg4MinStreams) k_msk_frontend_rb_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);
-    else k_msk_frontend_rb<<<S, 64, 0, c->stream>>>(c->d_streams, g, S);
+    else if (S > kFrontendWg4MinStreams) {
+        c->last_frontend = "k_msk_frontend_rb_wg4";
+        k_msk_frontend_rb_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);
+    } else {
+        c->last_frontend = "k_msk_frontend_rb";
+        k_msk_frontend_rb<<<S, 64, 0, c->stream>>>(c->d_streams, g, S);
+    }
     if (tm) { HIPCHK(hipEventRecord(c->ev[3], c->stream)); HIPCHK(hipEventRecord(c->ev[4], c->stream)); }
     k_sync_track<<<S, 64, 0, c->stream>>>(c->d_streams);
     if (tm) { HIPCHK(hipEventRecord(c->ev[5], c->stream)); HIPCHK(hipEventRecord(c->ev[6], c->stream)); }
@@ -501,6 +513,8 @@ extern "C" int opv_set_frontend(opv_ctx* c, int streams_per_wave) {
     c->frontend = streams_per_wave;
     return OPV_OK;
 }
+
+extern "C" const char* opv_frontend_kernel(opv_ctx* c) { return c ? c->last_frontend : ""; }
 
 extern "C" int opv_sync(opv_ctx* c) {
     if (!c) return fail(OPV_EINVAL, "null context");

@@ -32,7 +32,7 @@ EXPORTS = [
     "opv_attach_device_iq", "opv_process", "opv_sync", "opv_set_frontend", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_tap_soft", "opv_tap_chunks",
     "opv_tap_offset_energies", "opv_tap_wave_info", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_modulated_samples",
-    "opv_tx_modulate", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device",
+    "opv_tx_modulate", "opv_frontend_kernel", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device",
 ]
 
 
@@ -101,6 +101,8 @@ def lib():
         L.opv_process.argtypes = [C.c_void_p]
         L.opv_sync.argtypes = [C.c_void_p]
         L.opv_set_frontend.argtypes = [C.c_void_p, C.c_int]
+        L.opv_frontend_kernel.restype = C.c_char_p
+        L.opv_frontend_kernel.argtypes = [C.c_void_p]
         L.opv_reset_stream.argtypes = [C.c_void_p, C.c_int]
         L.opv_pop_frames.restype = C.c_long
         L.opv_pop_frames.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -213,6 +215,10 @@ class Demod:
 
     def set_frontend(self, streams_per_wave):
         _chk(lib().opv_set_frontend(self.h, int(streams_per_wave)))
+
+    def frontend_kernel(self):
+        """name of the front-end kernel the last process() launched"""
+        return lib().opv_frontend_kernel(self.h).decode()
 
     def reset(self, stream=-1):
         _chk(lib().opv_reset_stream(self.h, stream))

@@ -11,6 +11,45 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def run_rccl_selftest():
+    """BASELINE configs[4]'s RCCL leg on ONE GPU: bench.py with OPV_BENCH_FORCE_DIST=1 takes its N > 1 path
+    (init_process_group("nccl", device_id=...), sharding.gather_frames on the library's zero-copy device views,
+    all_reduce MAX of the step time) with a world of one rank. Run as a fresh child process; returns what it said."""
+    import os
+    import socket
+    import subprocess
+    import time
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(OPV_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NCCL_DEBUG="INFO",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "1", "--streams", "8", "--frames", "12", "--steps", "1",
+           "--warmup", "0", "--no-extras"]
+    t0 = time.time()
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    return {"cmd": "OPV_BENCH_FORCE_DIST=1 NCCL_DEBUG=INFO " + " ".join(cmd[1:]), "rc": p.returncode, "stdout": p.stdout,
+            "stderr": p.stderr, "seconds": time.time() - t0}
+
+
+def pytest_sessionstart(session):
+    """On a GPU box, under -m gpu: the RCCL self-test child runs FIRST, before this process has touched the GPU
+    (tests/test_gpu_multirank.py::test_bench_rccl_leg_executes_at_world_1 reads the result)."""
+    import os
+    expr = session.config.getoption("markexpr", "") or ""
+    if "gpu" not in expr or "not gpu" in expr or os.environ.get("OPV_SKIP_RCCL_SELFTEST"):
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:       # (counting devices does not initialise the GPU)
+            return
+        session.config._opv_rccl_selftest = run_rccl_selftest()
+    except Exception as e:                       # reported by the test, not here
+        session.config._opv_rccl_selftest = {"cmd": "", "rc": -1, "stdout": "", "stderr": repr(e), "seconds": 0.0}
+
+
 @pytest.fixture(scope="session")
 def golden():
     import json

@@ -81,11 +81,16 @@ def events_match(amd, got_ev, exp_ev):
 
 
 def no_ties(st, tag="", edge_ties=0, offset_ties=0):
-    """The two input classes the product reports instead of reproducing (reference src/opv-demod.cpp:272,291: a tone
-    choice decided by the rounding of the reference's own LO; :161,195: an offset-search winner inside the one-pass
-    evaluation's 1e-11 band) must not occur on ordinary captures: a regression that starts to hit them would otherwise pass."""
+    """The two input classes the product reports (include/opv_demod.h). edge_ties (reference src/opv-demod.cpp:272,291: a
+    tone choice decided by the rounding of the reference's own LO) is NOT reproduced and must not occur on ordinary
+    captures: a regression that starts to hit it would otherwise pass. offset_ties (:161,195) counts offset-search
+    candidates the near-tie guard re-evaluated in the reference's order - reproduced, the estimate is compared with the
+    oracle's wherever this is called - but a guard that fires on ordinary captures more than once in several hundred streams
+    (two fine candidates within 1e-11 where neighbours are ~1e-8 apart) would mean the one-pass evaluation lost accuracy.
+    offset_ties=None: counted by the caller."""
     assert st.edge_ties == edge_ties, f"{tag}: edge_ties {st.edge_ties} (expected {edge_ties})"
-    assert st.offset_ties == offset_ties, f"{tag}: offset_ties {st.offset_ties} (expected {offset_ties})"
+    if offset_ties is not None:
+        assert st.offset_ties == offset_ties, f"{tag}: offset_ties {st.offset_ties} (expected {offset_ties})"
 
 
 def check_stream(amd, got, exp, tag="", edge_ties=0, offset_ties=0):
