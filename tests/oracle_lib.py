@@ -494,3 +494,55 @@ def channel_model(iq, gain=1.0, f0_hz=0.0, sigma=0.0, seed=0):
     out[0::2] = np.clip(np.rint(yr), -32768, 32767).astype(np.int16)
     out[1::2] = np.clip(np.rint(yi), -32768, 32767).astype(np.int16)
     return out
+
+
+# ---------------------------------------------------------------------------------------
+def run_under_reference_modem(child, iq, piece=16384, recv_timeout=60.0, verbose_child=False):
+    """The boundary's real caller: the REFERENCE's `opv-modem -R -d <child>` (oracle/_ref/opv-modem, compiled from
+    src/opv-modem.cpp) forks, execs `<child> -s -r` on pipes (:696-717), forwards its stdin in 16 KB reads (:734,753),
+    reads exactly-134-byte records from the child non-blocking (:765-786) and sends each as one UDP datagram to
+    127.0.0.1:<port> (-r). `iq` is written to the parent's stdin in pieces of <= `piece` bytes, then stdin is closed.
+    Returns (list of datagrams in arrival order, parent's exit status, parent's stderr text)."""
+    import select
+    import socket
+    import subprocess
+    import time
+    modem = ref_binary("opv-modem")
+    assert modem is not None, "oracle/_ref/opv-modem is missing (make -C oracle ref, in the build container)"
+    rx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    rx.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 8 << 20)
+    rx.bind(("127.0.0.1", 0))
+    port = rx.getsockname()[1]
+    rx.setblocking(False)
+    args = [str(modem), "-R", "-r", str(port), "-d", str(child)] + (["-v"] if verbose_child else [])
+    p = subprocess.Popen(args, stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    data = memoryview(np.ascontiguousarray(_iq(iq)).tobytes())
+    grams = []
+
+    def drain():
+        while True:
+            try:
+                grams.append(rx.recv(65536))
+            except BlockingIOError:
+                return
+    err = []
+    import threading
+    th = threading.Thread(target=lambda: err.append(p.stderr.read()), daemon=True)
+    th.start()
+    for at in range(0, len(data), piece):
+        p.stdin.write(data[at:at + piece])        # (blocks while the child's pipe is full: the parent's own back-pressure)
+        drain()
+    p.stdin.close()
+    t_end = time.time() + recv_timeout
+    while p.poll() is None and time.time() < t_end:
+        select.select([rx], [], [], 0.05)
+        drain()
+    if p.poll() is None:
+        p.kill()
+        p.wait()
+        raise AssertionError("opv-modem -R did not finish: the child never closed its stdout?")
+    time.sleep(0.05)
+    drain()
+    th.join(5)
+    rx.close()
+    return grams, p.returncode, (err[0].decode("utf-8", "replace") if err else "")
