@@ -277,9 +277,11 @@ __device__ inline void role_await(uint32_t a, uint32_t want, double& v, uint32_t
 // ROLE 0 (1111 vs 1043 cycles per symbol at 64 streams): each wave's LDS round trips and cross-lane hazard slots are no
 // longer filled by the other loop's arithmetic, and the partner is waited for once per symbol. It is
 // never selected automatically (opv_set_frontend(ctx, -2)).
-template <int WPB, int ROLE, bool RMAC = false>
+template <int WPB, int ROLE, int BODY = 0>
 __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ streams, OpvGlobalCfg cfg, int n_streams,
                                                   unsigned char* lds_all) {
+    // BODY 0: products + permlane-swap reductions (`symbol`, round 1); 1: row-broadcast reduction (`symbol_r`, round 2)
+    constexpr bool RMAC = BODY != 0;
     static_assert(!RMAC || ROLE == 0, "the row-broadcast reduction is a variant of the one-wave mapping");
     constexpr bool kT = ROLE != 2;       // this wave runs the timing loop (and stages the tiles)
     constexpr bool kF = ROLE != 1;       // this wave runs the AFC (and logs the soft symbols)
@@ -910,6 +912,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             __builtin_amdgcn_sched_barrier(0);
 
             [[maybe_unused]] double pd = 0.0, cx = 0, cy = 0, sum = 1.0, dif = 0, dm_ = 1.0, ee, el;
+            [[maybe_unused]] uint64_t zmask = 0;
             if constexpr (!kFirst) {
                 // phase detector operands: dom * conj(prev) (ref :299), see `symbol`
                 const double dr = fma(sg, P2o, P1o), di = fma(-sg, P4o, P3o);
@@ -927,6 +930,11 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 // the divisor's guard against digital silence: sum + 1e-100 IS sum unless sum is 0 (a non-zero sum of
                 // products of window sums is far above 1e-84), and an add needs no canonicalised operand where fmax does
                 dm_ = sum + kc_tiny;
+                // The silence test's compare HERE, its branch 35 instructions later: a v_cmp whose mask a scalar branch reads in
+                // the next instruction costs the lone wave a VALU -> SALU round trip (measured: 798 -> 776 cycles per symbol
+                // although this form issues one instruction more, an s_cmp on the mask)
+                zmask = __builtin_amdgcn_fcmp(sum, 0.0, 1 /*FCMP_OEQ*/);
+                asm volatile("" : "+s"(zmask));
             } else {
                 ee = row_bcast<2>(sq, seln); el = row_bcast<3>(shv, seln);
             }
@@ -986,7 +994,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 pd = fma(pd, h, c01.x);
                 pd = fma(sx, pd, pd_off);
                 pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));  // sign of cy
-                if (__builtin_expect(uni_eq(sum, 0.0), 0)) {        // digital silence on either side
+                if (__builtin_expect(zmask != 0ull, 0)) {           // digital silence on either side (sum == 0, compared above)
                     const double dr = fma(sg, P2o, P1o), di = fma(-sg, P4o, P3o);
                     const double2 sp = silence_pd(dr, di, prv, soft < 0.0, fo_sum, n_soft + (((my_soft_off - soft_off0) & soft_bmask) >> 3),
                                                   P1o, P2o, P3o, P4o);
@@ -999,6 +1007,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             fo_sum = fo_sum_next;
             cur.a = P1o; cur.b = P2o; cur.c = P3o; cur.d = P4o;     // prev <- this symbol's on-time correlations (ref :309-310)
         };
+
         auto sym = [&](auto tag, PrevSums& cur, const PrevSums& prv) {
             if constexpr (RMAC) symbol_r(tag, cur, prv);
             else symbol(tag, cur, prv);
@@ -1116,14 +1125,14 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_rb(OpvStream* __
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[kTabOff + 257 * 48];
     load_atan_table_q<64>(lds_all + kTabOff);
     __syncthreads();
-    msk_frontend_body<1, 0, true>(streams, cfg, n_streams, lds_all);
+    msk_frontend_body<1, 0, 1>(streams, cfg, n_streams, lds_all);
 }
 extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_rb_wg4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
                                                                          int n_streams) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * kTabOff + 257 * 48];
     load_atan_table_q<256>(lds_all + 4 * kTabOff);
     __syncthreads();
-    msk_frontend_body<4, 0, true>(streams, cfg, n_streams, lds_all);
+    msk_frontend_body<4, 0, 1>(streams, cfg, n_streams, lds_all);
 }
 // two waves per stream: wave 0 = timing loop (ROLE 1), wave 1 = AFC (ROLE 2), on two SIMDs of one CU
 extern "C" __global__ __launch_bounds__(128) void k_msk_frontend_dual(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,

@@ -17,7 +17,7 @@ from pathlib import Path
 import numpy as np
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libopv_demod_hip.so"
+LIB_PATH = Path(os.environ.get("OPV_LIB", PKG / "libopv_demod_hip.so"))   # (OPV_LIB: dev switch, an experimental build of the same ABI)
 
 SPS = 40
 FRAME_BYTES = 134
