@@ -530,7 +530,8 @@ def main():
         out["extras"]["cpu_baseline_all_cores"] = cpu_all_cores(raw, n)
         out["setup"] = {"device_modulate_s_all_streams": round(t_mod, 2),
                         "device_modulate_one_stream": {"s": round(t_dev_mod, 3), "Msamples/s": round(n / t_dev_mod / 1e6, 1),
-                                                        "note": "opv_tx_modulate_device incl. host bit-level pass + H2D of codes"}}
+                                                        "note": "opv_tx_modulate_device end to end on a fresh context: 134 B/frame H2D, k_tx_encode, k_tx_scan_frames, "
+                                                                "k_tx_expand_phases (first call of a context), k_tx_modulate, count D2H + sync"}}
     elif rank == 0 and args.no_extras:
         out["cpu_baseline"] = None
     elif rank == 0:

@@ -217,14 +217,23 @@ int opv_decode_payloads(opv_ctx* ctx, const double* soft, size_t n_frames, uint8
  * Host-side, bit-identical to `opv-mod`: BERT frames (:339-361) and the whole
  * encode->interleave->MSK chain incl. 100 trailing zero symbols (:473-529). */
 void opv_tx_bert_frame(const char* callsign, uint32_t token, uint32_t frame_num, uint8_t out134[OPV_FRAME_BYTES]);
+/* n_frames consecutive BERT frames (frame numbers first_frame, first_frame + 1, ...) into out134[n_frames][134] */
+void opv_tx_bert_frames(const char* callsign, uint32_t token, uint32_t first_frame, size_t n_frames, uint8_t* out134);
 size_t opv_tx_modulated_samples(size_t n_frames);
 size_t opv_tx_modulate(const uint8_t* frames134, size_t n_frames, int16_t* iq_out);
-/* Device-side modulator: same result as opv_tx_modulate, written straight
- * into HBM (d_iq_out: device pointer, 16-byte aligned, opv_tx_modulated_samples(n_frames) samples).
- * Bit-level work stays on the host; samples whose truncation could differ between device sincos
- * and libm are re-evaluated on the host. Returns the number of samples so patched (>= 0, normally
- * 0) or a negative error. */
+/* Device-side transmit chain: same result as opv_tx_modulate, written straight into HBM
+ * (d_iq_out: device pointer, 16-byte aligned, opv_tx_modulated_samples(n_frames) samples). The whole chain of
+ * src/opv-mod.cpp:97-291 runs on the device: randomiser, convolutional encoder, interleaver and sync word per frame
+ * (k_tx_encode), the differential sign as a parity prefix over the run (k_tx_scan_frames), the two free-running NCOs
+ * (k_tx_expand_phases, from a build-time table of their state every 128th symbol; once per context and run length, shared by
+ * every stream), sample synthesis (k_tx_modulate). `frames134` is a host pointer (134 bytes per frame cross PCIe). Samples
+ * whose truncation could differ between device sincos and libm are re-evaluated on the host. Returns the number of samples so
+ * patched (>= 0, normally 0) or a negative error. Synchronous. */
 long opv_tx_modulate_device(opv_ctx* ctx, const uint8_t* frames134, size_t n_frames, int16_t* d_iq_out);
+/* Parity tap: entries [first, first + count) of the NCO checkpoint sequence the device transmit chain starts from - (ph1, ph2)
+ * of src/opv-mod.cpp:274-279 at symbol 128 * entry of a run - from the build-time table, beyond it (4096 frames) from the host
+ * continuation. Host only, needs no device. */
+void opv_tap_tx_checkpoints(size_t first, size_t count, double* out2);
 /* Device-side channel tool for synthetic multi-stream workloads:
  * d_out[n] = clip(rint(gain * d_in[n] * exp(j 2 pi f0 n / Fs) + sigma * N(0,1)+jN(0,1))),
  * noise from a counter-based generator keyed by (seed, n). d_in/d_out: device int16 IQ. */

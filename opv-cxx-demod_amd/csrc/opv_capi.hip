@@ -31,7 +31,10 @@ extern "C" __global__ void k_frame_decode(OpvStream*, uint32_t);
 extern "C" __global__ void k_decode_payloads(const double*, uint32_t, uint8_t*, int32_t*, int8_t*, int8_t*, uint8_t*);
 extern "C" __global__ void k_channel(const int4*, int4*, uint64_t, double, double, double, uint64_t);
 extern "C" __global__ void k_resample_clock(const int*, uint64_t, int*, uint64_t, double);
-extern "C" __global__ void k_tx_modulate(const int8_t*, const double2*, uint64_t, int*, uint32_t*, uint64_t*, uint32_t);
+extern "C" __global__ void k_tx_encode(const uint8_t*, uint32_t, uint8_t*, uint8_t*);
+extern "C" __global__ void k_tx_scan_frames(uint8_t*, uint32_t);
+extern "C" __global__ void k_tx_expand_phases(const double2*, uint32_t, uint64_t, uint64_t, double2*);
+extern "C" __global__ void k_tx_modulate(const uint8_t*, const uint8_t*, const double2*, uint64_t, uint64_t, int*, uint32_t*, uint64_t*, uint32_t);
 
 namespace {
 
@@ -138,11 +141,18 @@ struct opv_ctx {
     // Back-pressure: a stream that paused in the last round (OpvStream.stalled) must be retried by the next
     // opv_process even if the caller pushed nothing new. Unknown (= true) from a launch until the next refresh().
     bool maybe_stalled = false;
-    // device modulator cache: NCO phases at symbol starts (data-independent, grown on demand)
-    std::vector<double> tx_phases;       // host copy, 2 doubles per symbol
-    double tx_ph1 = 0.0, tx_ph2 = 0.0;   // phases after the last cached symbol
-    double* d_tx_phases = nullptr;
-    size_t d_tx_phases_cap = 0;          // symbols
+    // device transmit chain: NCO phases at symbol starts (data-independent: expanded once per context and run length from
+    // the build-time checkpoint table, shared by every stream modulated afterwards) + grow-only scratch
+    double* d_tx_ckpt = nullptr;         // checkpoints uploaded so far, 2 doubles each
+    size_t tx_ckpt_cap = 0, tx_ckpt_have = 0;
+    double* d_tx_phases = nullptr;       // (ph1, ph2) at every symbol start
+    size_t tx_phases_cap = 0, tx_phases_have = 0;   // symbols
+    uint8_t* d_tx_frames = nullptr;      // [frames][134]
+    uint8_t* d_tx_codes = nullptr;       // one code byte per symbol
+    uint8_t* d_tx_fpar = nullptr;        // per-frame parity / prefix
+    size_t tx_frames_cap = 0;            // frames the three scratch buffers hold
+    uint32_t* d_tx_cnt = nullptr;        // ambiguous-sample counter + list
+    uint64_t* d_tx_list = nullptr;
     const char* last_frontend = "";   // kernel the last opv_process launched for the front-end (opv_frontend_kernel)
     int frontend = 0;  // 0: by stream count, 1: one wave per stream, 4: four streams per wave, -1 / -2: see opv_set_frontend
     bool timing = false;
@@ -316,7 +326,7 @@ extern "C" void opv_destroy(opv_ctx* c) {
     }
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_counts, c->d_tx_phases, c->d_offs_wtab};
+    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_counts, c->d_tx_phases, c->d_offs_wtab, c->d_tx_ckpt, c->d_tx_frames, c->d_tx_codes, c->d_tx_fpar, c->d_tx_cnt, c->d_tx_list};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -816,58 +826,86 @@ extern "C" long opv_resample_device(opv_ctx* c, const int16_t* d_in, size_t n_in
 extern "C" long opv_tx_modulate_device(opv_ctx* c, const uint8_t* frames, size_t n_frames, int16_t* d_iq_out) {
     if (!c || !d_iq_out || (!frames && n_frames)) return fail(OPV_EINVAL, "null argument");
     if (((uintptr_t)d_iq_out & 15u) != 0) return fail(OPV_EINVAL, "device IQ pointer must be 16-byte aligned");
+    if (n_frames > 0x7FFFFFFFull / OPV_FSYMS) return fail(OPV_EINVAL, "opv_tx_modulate_device: too many frames for one call");
     HIPCHK(hipSetDevice(c->cfg.device));
     const size_t nsym = n_frames * OPV_FSYMS, nsym_total = nsym + 100;  // + 100 silent symbols (opv-mod.cpp:528-529)
-    // symbol-start phases: extend the cache with the reference's own accumulation, upload once
-    if (c->tx_phases.size() < 2 * nsym) {
-        const size_t have = c->tx_phases.size() / 2;
-        c->tx_phases.resize(2 * nsym);
-        opv_tx_symbol_phases(have, nsym - have, &c->tx_ph1, &c->tx_ph2, c->tx_phases.data() + 2 * have);
-    }
-    if (c->d_tx_phases_cap < nsym) {
-        if (c->d_tx_phases) HIPCHK(hipFree(c->d_tx_phases));
-        c->d_tx_phases = nullptr;
-        c->d_tx_phases_cap = 0;
-        if (nsym) HIPCHK(hipMalloc(&c->d_tx_phases, sizeof(double) * 2 * nsym));
-        c->d_tx_phases_cap = nsym;
-        if (nsym) HIPCHK(hipMemcpy(c->d_tx_phases, c->tx_phases.data(), sizeof(double) * 2 * nsym, hipMemcpyHostToDevice));
-    }
-    std::vector<int8_t> amp(nsym_total, 0);
-    opv_tx_symbol_codes(frames, n_frames, amp.data());
-    int8_t* d_amp = nullptr;
-    uint32_t* d_cnt = nullptr;
-    uint64_t* d_list = nullptr;
     constexpr uint32_t kAmbCap = 4096;
-    int rc = OPV_OK;
-    auto chk = [&](hipError_t e, const char* w) { if (e != hipSuccess && rc == OPV_OK) rc = fail(OPV_EHIP, w, e); };
-    chk(hipMalloc(&d_amp, nsym_total), "hipMalloc amp");
-    chk(hipMalloc(&d_cnt, sizeof(uint32_t)), "hipMalloc amb_count");
-    chk(hipMalloc(&d_list, sizeof(uint64_t) * kAmbCap), "hipMalloc amb_list");
-    long patched = 0;
-    if (rc == OPV_OK) {
-        chk(hipMemcpyAsync(d_amp, amp.data(), nsym_total, hipMemcpyHostToDevice, c->stream), "H2D amp");
-        chk(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t), c->stream), "memset");
-        const unsigned blocks = (unsigned)((nsym_total + 63) / 64);
-        k_tx_modulate<<<blocks, 64, 0, c->stream>>>(d_amp, (const double2*)c->d_tx_phases, nsym_total, (int*)d_iq_out,
-                                                    d_cnt, d_list, kAmbCap);
-        chk(hipGetLastError(), "k_tx_modulate launch");
-        uint32_t n_amb = 0;
-        chk(hipMemcpyAsync(&n_amb, d_cnt, sizeof n_amb, hipMemcpyDeviceToHost, c->stream), "D2H count");
-        chk(hipStreamSynchronize(c->stream), "sync");
-        if (rc == OPV_OK && n_amb > kAmbCap) rc = fail(OPV_ECAPACITY, "too many ambiguous samples (internal)");
-        if (rc == OPV_OK && n_amb) {  // re-evaluate with libm exactly like the reference
-            std::vector<uint64_t> list(n_amb);
-            chk(hipMemcpy(list.data(), d_list, sizeof(uint64_t) * n_amb, hipMemcpyDeviceToHost), "D2H list");
-            for (uint64_t n : list) {
-                const size_t sym = n / OPV_SPS;
-                int16_t iq[2];
-                opv_tx_sample_exact(c->tx_phases[2 * sym], c->tx_phases[2 * sym + 1], amp[sym], (int)(n % OPV_SPS), &iq[0], &iq[1]);
-                chk(hipMemcpy(d_iq_out + 2 * n, iq, 4, hipMemcpyHostToDevice), "H2D patch");
+    // ---- symbol-start phases: from the checkpoint table, expanded on the device, once per context and run length
+    if (c->tx_phases_have < nsym) {
+        const size_t need_ck = (nsym + OPV_TX_CKPT_SYMS - 1) / OPV_TX_CKPT_SYMS;
+        if (c->tx_ckpt_have < need_ck) {
+            if (c->tx_ckpt_cap < need_ck) {
+                if (c->d_tx_ckpt) HIPCHK(hipFree(c->d_tx_ckpt));
+                c->d_tx_ckpt = nullptr;
+                c->tx_ckpt_cap = c->tx_ckpt_have = 0;
+                HIPCHK(hipMalloc(&c->d_tx_ckpt, sizeof(double) * 2 * need_ck));
+                c->tx_ckpt_cap = need_ck;
             }
-            patched = (long)n_amb;
+            std::vector<double> ck(2 * (need_ck - c->tx_ckpt_have));
+            opv_tx_checkpoint_range(c->tx_ckpt_have, need_ck - c->tx_ckpt_have, ck.data());
+            HIPCHK(hipMemcpy(c->d_tx_ckpt + 2 * c->tx_ckpt_have, ck.data(), sizeof(double) * ck.size(), hipMemcpyHostToDevice));
+            c->tx_ckpt_have = need_ck;
+        }
+        size_t first_ck = c->tx_phases_have / OPV_TX_CKPT_SYMS;            // whole intervals already expanded stay
+        if (c->tx_phases_cap < nsym) {
+            HIPCHK(hipStreamSynchronize(c->stream));                        // (an earlier modulation may still read the old table)
+            if (c->d_tx_phases) HIPCHK(hipFree(c->d_tx_phases));
+            c->d_tx_phases = nullptr;
+            c->tx_phases_cap = c->tx_phases_have = 0;
+            HIPCHK(hipMalloc(&c->d_tx_phases, sizeof(double) * 2 * nsym));
+            c->tx_phases_cap = nsym;
+            first_ck = 0;
+        }
+        const size_t n_new = need_ck - first_ck;
+        k_tx_expand_phases<<<(unsigned)((n_new + 63) / 64), 64, 0, c->stream>>>((const double2*)c->d_tx_ckpt, (uint32_t)need_ck, first_ck,
+                                                                                 nsym, (double2*)c->d_tx_phases);
+        HIPCHK(hipGetLastError());
+        c->tx_phases_have = nsym;
+    }
+    // ---- scratch (grow-only)
+    if (c->tx_frames_cap < n_frames || !c->d_tx_cnt) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        void* old[] = {c->d_tx_frames, c->d_tx_codes, c->d_tx_fpar};
+        for (void* p : old) if (p) HIPCHK(hipFree(p));
+        c->d_tx_frames = c->d_tx_codes = c->d_tx_fpar = nullptr;
+        c->tx_frames_cap = 0;
+        const size_t cap = n_frames ? n_frames : 1;
+        HIPCHK(hipMalloc(&c->d_tx_frames, cap * OPV_FB));
+        HIPCHK(hipMalloc(&c->d_tx_codes, cap * OPV_FSYMS));
+        HIPCHK(hipMalloc(&c->d_tx_fpar, cap));
+        c->tx_frames_cap = cap;
+        if (!c->d_tx_cnt) HIPCHK(hipMalloc(&c->d_tx_cnt, sizeof(uint32_t)));
+        if (!c->d_tx_list) HIPCHK(hipMalloc(&c->d_tx_list, sizeof(uint64_t) * kAmbCap));
+    }
+    // ---- frames -> code bytes + frame prefixes -> samples, all on the context's stream
+    if (n_frames) HIPCHK(hipMemcpyAsync(c->d_tx_frames, frames, n_frames * OPV_FB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_tx_cnt, 0, sizeof(uint32_t), c->stream));
+    if (n_frames) {
+        k_tx_encode<<<(unsigned)n_frames, 256, 0, c->stream>>>(c->d_tx_frames, (uint32_t)n_frames, c->d_tx_codes, c->d_tx_fpar);
+        k_tx_scan_frames<<<1, 1024, 0, c->stream>>>(c->d_tx_fpar, (uint32_t)n_frames);
+    }
+    k_tx_modulate<<<(unsigned)((nsym_total + 63) / 64), 64, 0, c->stream>>>(c->d_tx_codes, c->d_tx_fpar, (const double2*)c->d_tx_phases, nsym,
+                                                                          nsym_total, (int*)d_iq_out, c->d_tx_cnt, c->d_tx_list, kAmbCap);
+    HIPCHK(hipGetLastError());
+    uint32_t n_amb = 0;
+    HIPCHK(hipMemcpyAsync(&n_amb, c->d_tx_cnt, sizeof n_amb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));                                // (also: `frames` is the caller's again)
+    if (n_amb > kAmbCap) return fail(OPV_ECAPACITY, "too many ambiguous samples (internal)");
+    if (n_amb) {  // re-evaluate with libm exactly like the reference: tone / sign and phases of those symbols on the host
+        std::vector<uint64_t> list(n_amb);
+        HIPCHK(hipMemcpy(list.data(), c->d_tx_list, sizeof(uint64_t) * n_amb, hipMemcpyDeviceToHost));
+        std::vector<int8_t> amp(nsym_total, 0);
+        opv_tx_symbol_codes(frames, n_frames, amp.data());
+        std::vector<double> ph(2 * OPV_TX_CKPT_SYMS);
+        for (uint64_t n : list) {
+            const size_t sym = n / OPV_SPS, ck = sym / OPV_TX_CKPT_SYMS, in = sym - ck * OPV_TX_CKPT_SYMS;
+            double p[2];
+            opv_tx_checkpoint_range(ck, 1, p);
+            opv_tx_symbol_phases(0, in + 1, &p[0], &p[1], ph.data());
+            int16_t iq[2];
+            opv_tx_sample_exact(ph[2 * in], ph[2 * in + 1], amp[sym], (int)(n % OPV_SPS), &iq[0], &iq[1]);
+            HIPCHK(hipMemcpy(d_iq_out + 2 * n, iq, 4, hipMemcpyHostToDevice));
         }
     }
-    void* ptrs[] = {d_amp, d_cnt, d_list};
-    for (void* p : ptrs) if (p) (void)hipFree(p);
-    return rc == OPV_OK ? patched : rc;
+    return (long)n_amb;
 }

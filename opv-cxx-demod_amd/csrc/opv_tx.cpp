@@ -14,7 +14,9 @@
 // tone contributes an exact +/-0 — then runs frame-parallel on host threads.
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -105,6 +107,11 @@ extern "C" void opv_tx_bert_frame(const char* callsign, uint32_t token, uint32_t
     for (unsigned i = 0; i < OPV_FRAME_BYTES - 12; ++i) out[12 + i] = (uint8_t)(frame_num + i);
 }
 
+extern "C" void opv_tx_bert_frames(const char* callsign, uint32_t token, uint32_t first_frame, size_t n_frames,
+                                   uint8_t* out) {
+    for (size_t k = 0; k < n_frames; ++k) opv_tx_bert_frame(callsign, token, first_frame + (uint32_t)k, out + k * OPV_FRAME_BYTES);
+}
+
 extern "C" size_t opv_tx_modulated_samples(size_t n_frames) {
     return n_frames * (size_t)OPV_FRAME_SYMBOLS * kSps + 100u * kSps;
 }
@@ -140,6 +147,39 @@ void opv_tx_symbol_phases(size_t first_symbol, size_t n_symbols, double* ph1_io,
     *ph1_io = ph1;
     *ph2_io = ph2;
 }
+
+#ifndef OPV_TX_NO_EMBEDDED_TABLE   // (the build-time tool that MAKES the table links this file without it)
+void opv_tx_checkpoint_range(size_t first, size_t count, double* out2) {
+    size_t n_tab = 0;
+    const double* tab = opv_tx_checkpoints(&n_tab);
+    // dev switch (read once): pretend the table is shorter, so that tests reach the host continuation at small sizes
+    static const size_t limit = [] { const char* e = std::getenv("OPV_TX_CKPT_LIMIT"); return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)-1; }();
+    if (limit >= 1 && limit < n_tab) n_tab = limit;
+    size_t k = 0;
+    for (; k < count && first + k < n_tab; ++k) { out2[2 * k] = tab[2 * (first + k)]; out2[2 * k + 1] = tab[2 * (first + k) + 1]; }
+    if (k == count) return;
+    // beyond the build-time table: the same recurrence, continued from its last entry, kept for the life of the process
+    static std::mutex mu;
+    static std::vector<double> ext;      // entries n_tab, n_tab + 1, ... (2 doubles each)
+    static double ph1, ph2;              // state at entry n_tab + ext.size() / 2
+    std::lock_guard<std::mutex> lock(mu);
+    if (ext.empty() && n_tab) { ph1 = tab[2 * (n_tab - 1)]; ph2 = tab[2 * (n_tab - 1) + 1]; }
+    std::vector<double> tmp(2 * OPV_TX_CKPT_SYMS);
+    for (; k < count; ++k) {
+        const size_t e = first + k - n_tab;                  // index into ext
+        while (ext.size() / 2 <= e) {
+            // entry n_tab + j is one checkpoint interval behind entry n_tab + j - 1 (the table's last entry for j = 0)
+            opv_tx_symbol_phases(0, OPV_TX_CKPT_SYMS, &ph1, &ph2, tmp.data());
+            ext.push_back(ph1);
+            ext.push_back(ph2);
+        }
+        out2[2 * k] = ext[2 * e];
+        out2[2 * k + 1] = ext[2 * e + 1];
+    }
+}
+
+extern "C" void opv_tap_tx_checkpoints(size_t first, size_t count, double* out2) { opv_tx_checkpoint_range(first, count, out2); }
+#endif
 
 void opv_tx_sample_exact(double ph1_sym, double ph2_sym, int a, int i, int16_t* I, int16_t* Q) {
     const double inc1 = kTwoPi * (-kDev) / kFs, inc2 = kTwoPi * (+kDev) / kFs;

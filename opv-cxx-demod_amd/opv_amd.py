@@ -31,8 +31,8 @@ EXPORTS = [
     "opv_create", "opv_destroy", "opv_last_error", "opv_abi_version", "opv_push_iq", "opv_push_iq_batch", "opv_flush",
     "opv_attach_device_iq", "opv_process", "opv_sync", "opv_set_frontend", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_tap_soft", "opv_tap_chunks",
-    "opv_tap_offset_energies", "opv_tap_wave_info", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_modulated_samples",
-    "opv_tx_modulate", "opv_frontend_kernel", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device",
+    "opv_tap_offset_energies", "opv_tap_wave_info", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_bert_frames", "opv_tx_modulated_samples",
+    "opv_tx_modulate", "opv_tap_tx_checkpoints", "opv_frontend_kernel", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device",
 ]
 
 
@@ -123,6 +123,10 @@ def lib():
                                           C.c_void_p, C.c_void_p, C.c_void_p]
         L.opv_tx_bert_frame.restype = None
         L.opv_tx_bert_frame.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.opv_tx_bert_frames.restype = None
+        L.opv_tx_bert_frames.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_size_t, C.c_void_p]
+        L.opv_tap_tx_checkpoints.restype = None
+        L.opv_tap_tx_checkpoints.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p]
         L.opv_tx_modulated_samples.restype = C.c_size_t
         L.opv_tx_modulated_samples.argtypes = [C.c_size_t]
         L.opv_tx_modulate.restype = C.c_size_t
@@ -148,8 +152,14 @@ def _chk(rc):
 # ---------------------------------------------------------------- transmit side (host)
 def bert_frames(n, callsign="W5NYV", token=0xBBAADD, first=0):
     out = np.zeros((n, FRAME_BYTES), np.uint8)
-    for k in range(n):
-        lib().opv_tx_bert_frame(callsign.encode(), token, first + k, out[k].ctypes.data)
+    lib().opv_tx_bert_frames(callsign.encode(), token, first, n, out.ctypes.data)
+    return out
+
+
+def tx_checkpoints(first, count):
+    """(ph1, ph2) of the modulator's NCOs at symbols 128 * (first .. first + count - 1) of a run (parity tap)"""
+    out = np.empty((count, 2), np.float64)
+    lib().opv_tap_tx_checkpoints(first, count, out.ctypes.data)
     return out
 
 

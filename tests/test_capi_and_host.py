@@ -167,3 +167,37 @@ def test_alignment_pass_verifies_its_own_output():
     for bad in ([[0, 8, "v_add_f32_e64", "v0, v1, v3"]] + same["k"][1:], [[0, 8, "v_sub_f32_e64", "v0, v1, v2"]] + same["k"][1:], same["k"][:-1]):
         with pytest.raises(SystemExit):
             al.verify(before, {"k": bad}, {"k": [0]})
+
+
+def _replay_interval(ph1, ph2, n_samples):
+    """the reference's NCO recurrence (src/opv-mod.cpp:274-279) in numpy scalars: rounded adds, while-loop wraps"""
+    pi = np.float64(3.14159265358979323846)
+    two_pi = np.float64(2.0) * pi
+    inc1 = two_pi * np.float64(-13550.0) / np.float64(2168000.0)
+    inc2 = two_pi * np.float64(13550.0) / np.float64(2168000.0)
+    a, b = np.float64(ph1), np.float64(ph2)
+    for _ in range(n_samples):
+        a = a + inc1
+        while a > pi: a = a - two_pi
+        while a < -pi: a = a + two_pi
+        b = b + inc2
+        while b > pi: b = b - two_pi
+        while b < -pi: b = b + two_pi
+    return float(a), float(b)
+
+
+def test_tx_checkpoint_table_is_the_reference_recurrence(amd):
+    """The build-time table the device transmit chain starts from (tools/gen_tx_checkpoints.cpp, embedded by
+    csrc/opv_tx_ckpt.cpp): entry 0 is the reset state, every entry is its predecessor advanced by 128 x 40 samples of the
+    reference's NCO recurrence - checked at the start, in the middle, across the END of the table (entries 69376 -> 69377
+    -> 69378: the last tabulated one and the first two of the host continuation) - bit for bit."""
+    ck = amd.tx_checkpoints(0, 6)
+    assert ck[0, 0] == 0.0 and ck[0, 1] == 0.0
+    for j in range(5):
+        assert _replay_interval(ck[j, 0], ck[j, 1], 128 * 40) == (ck[j + 1, 0], ck[j + 1, 1]), j
+    n_tab = 4096 * 2168 // 128                       # entries 0 .. n_tab are tabulated (the last one is where longer runs continue)
+    for first in (31337, n_tab - 1, n_tab, n_tab + 1):
+        a = amd.tx_checkpoints(first, 2)
+        assert _replay_interval(a[0, 0], a[0, 1], 128 * 40) == (a[1, 0], a[1, 1]), first
+    # and the table agrees with the host modulator's own phase walk (what opv-mod's sha256 pins cover): symbol 128 * 7
+    assert tuple(amd.tx_checkpoints(7, 1)[0]) == _replay_interval(0.0, 0.0, 7 * 128 * 40)

@@ -557,6 +557,53 @@ def test_device_modulator_is_bit_identical_to_host_and_reference(amd, golden):
     d.close()
 
 
+def test_device_transmit_chain_lengths_order_and_table_end(amd, golden):
+    """The device transmit chain end to end (k_tx_encode -> k_tx_scan_frames -> k_tx_expand_phases -> k_tx_modulate):
+    run lengths in ANY order on one context (the phase table grows and is re-used: 3, 1000, 40 frames; 1000 = BASELINE
+    configs[1]'s capture, sha256 = `opv-mod -S W5NYV -B 1000`), adversarial payloads (all ones / all zeros / alternating: the
+    differential sign and the tone choice at their extremes), and - in a child process with OPV_TX_CKPT_LIMIT=16, so that
+    the build-time NCO table ends after 16 entries = 2048 symbols - a 100-frame run that continues on the host recurrence."""
+    import subprocess
+    import sys
+    import torch
+    _, meta = golden
+    pins = meta["opv_mod_bert_W5NYV"]
+    dev = torch.device("cuda", 0)
+    d = amd.Demod(1, max_samples=1 << 20)
+    for nfr in (3, 1000, 40):
+        frames = amd.bert_frames(nfr)
+        n = amd.lib().opv_tx_modulated_samples(nfr)
+        out = torch.empty(2 * n, dtype=torch.int16, device=dev)
+        d.modulate_device(frames, out.data_ptr())
+        got = out.cpu().numpy()
+        if nfr == 1000:
+            assert hashlib.sha256(got.tobytes()).hexdigest() == pins["1000"]["sha256"]
+        else:
+            assert np.array_equal(got, amd.modulate(frames)), nfr
+    pat = np.stack([np.full(134, 0xFF, np.uint8), np.zeros(134, np.uint8), np.full(134, 0xAA, np.uint8), np.full(134, 0x55, np.uint8),
+                    np.arange(134, dtype=np.uint8)] * 3)
+    n = amd.lib().opv_tx_modulated_samples(len(pat))
+    out = torch.empty(2 * n, dtype=torch.int16, device=dev)
+    d.modulate_device(pat, out.data_ptr())
+    assert np.array_equal(out.cpu().numpy(), amd.modulate(pat))
+    d.close()
+    child = (
+        "import hashlib, sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {str(ROOT)!r})\n"
+        "from __graft_entry__ import load_opv_amd\n"
+        "amd = load_opv_amd()\n"
+        "fr = amd.bert_frames(100)\n"
+        "n = amd.lib().opv_tx_modulated_samples(100)\n"
+        "out = torch.empty(2 * n, dtype=torch.int16, device='cuda')\n"
+        "d = amd.Demod(1, max_samples=1 << 20)\n"
+        "d.modulate_device(fr, out.data_ptr())\n"
+        "print(hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest())\n")
+    env = dict(os.environ, OPV_TX_CKPT_LIMIT="16")
+    r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == pins["100"]["sha256"]
+
+
 def test_batch_mode_100_frames_noisy(amd, oracle, iq100):
     """Batch mode = ONE demodulate() over the whole capture (reference :1173): pos runs to 8.7e6
     (fp64 resolution of the sample position matters there) and there are no chunk artefacts."""
