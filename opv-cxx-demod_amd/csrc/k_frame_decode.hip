@@ -7,9 +7,11 @@
 //
 // Bit-exactness. Everything after the quantiser is integer. The quantiser itself
 // (:856-866) is reproduced operation for operation: the scale is the SEQUENTIAL fp64 sum of
-// |soft| (every lane runs the same 2144 dependent adds out of LDS — redundant, uniform, and
-// cheap next to the front-end), then one IEEE divide, one multiply, two adds and a
-// truncation per symbol with FMA contraction disabled. Given the same 2144 doubles this
+// |soft| in index order - 2144 dependent additions, which a wave-per-frame kernel can only run
+// redundantly on its 64 lanes (round 2: 4.8 k of the 35 k instructions of a frame). They now run in a
+// pre-pass with one FRAME per lane (k_frame_scale / k_payload_scale: 64 frames' sums side by side, same
+// additions in the same order), and the decoder reads the scale - then one IEEE divide, one multiply,
+// two adds and a truncation per symbol with FMA contraction disabled. Given the same 2144 doubles this
 // kernel returns the same bytes, decisions and metric as the reference, always.
 //
 // Viterbi on a wave: the 64 path metrics live one per lane (int32) under a ROTATING state-to-lane
@@ -26,8 +28,10 @@
 // (:887-895; the LFSR restarts at 0xFF every frame so it is a constant 134-byte table).
 // (The index algebra was checked against the oracle's decoder in a numpy model before it was written.)
 //
-// Bytes: 17 152 B of soft symbols in, 134 B out per frame (L2-resident right after the
-// front-end). Integer ACS rate: 68 608 ACS/frame. No MFMA.
+// Bytes: 17 152 B of soft symbols in (read twice: pre-pass and quantiser, the second time from L2), 134 B out per
+// frame. With the scale known up front the soft doubles are never staged in LDS: a lane quantises straight into the
+// deinterleaved position (a gather of 8-byte words inside the frame's 17 KB; a trellis step's two 3-bit values share a
+// byte), and a frame needs 9.8 KB of LDS instead of 17.3 KB - sixteen frames per CU (four waves per SIMD) instead of nine. Integer ACS rate: 68 608 ACS/frame. No MFMA.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -54,6 +58,8 @@ constexpr LfsrTable make_lfsr() {  // ref :887-893
 }
 __constant__ LfsrTable kLfsr = make_lfsr();
 
+__device__ inline uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 __device__ inline uint32_t deint_addr(uint32_t i) {  // ref :792-795
     const uint32_t p = (i & 31u) * 67u + (i >> 5);
     return (p & ~7u) + (7u - (p & 7u));
@@ -65,57 +71,58 @@ struct DecodeTaps {
     uint8_t* bits;  // [n][1072] or null
 };
 
-// The whole FrameDecoder::decode for one frame, executed by one wave.
-__device__ __forceinline__ void decode_one(const double* __restrict__ soft, uint32_t first, uint32_t mask,
+// sum |soft| of one payload in index order, divided by its length (ref :856-858): ONE lane's work. 64 lanes walk 64
+// payloads, i.e. every load instruction touches 64 different cache lines: 16 bytes per lane and load (the ring is only
+// 8-byte aligned at a payload's first symbol; unaligned 16-byte global loads are fine) unless the payload wraps the ring.
+__device__ __forceinline__ double payload_scale(const double* __restrict__ soft, uint32_t first, uint32_t mask) {
+    typedef double __attribute__((ext_vector_type(2), aligned(8))) double2u;        // 16-byte load, 8-byte aligned
+    double sum = 0.0;
+    first &= mask;
+    if ((uint64_t)first + OPV_CODED - 1u <= (uint64_t)mask) {
+        const double2u* p = reinterpret_cast<const double2u*>(soft + first);
+        for (uint32_t i = 0; i < OPV_CODED / 2; i += 8) {
+            double2u v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p[i + j];                                 // eight loads in flight
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sum += fabs(v[j].x); sum += fabs(v[j].y); }    // strictly in index order, like the reference's loop
+        }
+    } else {
+        for (uint32_t i = 0; i < OPV_CODED; ++i) sum += fabs(soft[(first + i) & mask]);
+    }
+    return sum / (double)OPV_CODED;
+}
+
+// FrameDecoder::decode for one frame behind its scale (ref :859-898), executed by one wave.
+__device__ __forceinline__ void decode_one(const double* __restrict__ soft, uint32_t first, uint32_t mask, double scale,
                                   uint8_t* __restrict__ out,
                                   int32_t* __restrict__ metric_out, int8_t* tq, int8_t* td, uint8_t* tb,
                                   unsigned char* lds) {
     const int lane = threadIdx.x;
-    // LDS: the 2144 soft doubles are dead once quantised, so everything after them lives in their space.
-    // 17.3 KB per frame instead of 30 KB: nine frames per CU, i.e. two waves per SIMD hiding each other's
-    // latencies (measured: 9.3 -> 5.6 ms per 64 000 frames from this alone).
-    // s_q overlays the soft values it is computed from: lane l writes byte i = l + 64 it after ALL lanes of
-    // the wave have read soft[64 it .. 64 it + 63] (bytes >= 512 it), so nothing unread is overwritten.
-    double* s_soft = reinterpret_cast<double*>(lds);                                 // 17 152 B
-    uint8_t* s_q = lds;                                                              //  2 144 B (over s_soft)
-    uint8_t* s_d = lds + OPV_CODED;                                                  //  2 144 B (after quantising)
-    unsigned long long* s_dec = reinterpret_cast<unsigned long long*>(lds + 2 * OPV_CODED);  // 8 576 B (4288 is 8-aligned)
-    uint8_t* s_out = lds + 17152;                                                    //    136 B
+    uint8_t* s_d = lds;                                                              //  1 072 B: the step's two 3-bit values, one per nibble
+    unsigned long long* s_dec = reinterpret_cast<unsigned long long*>(lds + OPV_FBITS);      //  8 576 B decision words (1072 is 8-aligned)
+    uint8_t* s_out = lds + OPV_FBITS + 8 * OPV_FBITS;                                //    136 B
 
-    for (int i = lane; i < OPV_CODED; i += 64) s_soft[i] = soft[(first + (uint32_t)i) & mask];  // ring or linear (mask = ~0)
-    __syncthreads();
-
-    // ---- scale = mean |soft|, summed in index order (ref :856-858) --------------------------
-    double scale = 0.0;
-    {
-        const double2* s2 = reinterpret_cast<const double2*>(s_soft);   // 16-byte LDS reads (same address in every lane: a broadcast)
-#pragma unroll 8
-        for (int i = 0; i < OPV_CODED / 2; ++i) {
-            const double2 v = s2[i];
-            scale += fabs(v.x);                                          // strictly in index order, like the reference's loop
-            scale += fabs(v.y);
-        }
-    }
-    scale /= (double)OPV_CODED;
     if (scale < 1e-10) {  // ref :859 — frame silently dropped
         if (lane == 0) *metric_out = -1;
         return;
     }
-
-    // ---- quantise (ref :862-866): q=0 confident bit 0 ... q=7 confident bit 1 ----------------
-    for (int i = lane; i < OPV_CODED; i += 64) {
-        const double nrm = (-s_soft[i] / scale) * 3.5 + 3.5;  // contraction is off for this TU
-        int v = (int)(nrm + 0.5);                             // C truncation toward zero
-        v = v < 0 ? 0 : (v > 7 ? 7 : v);
-        s_q[i] = (uint8_t)v;
-        if (tq) tq[i] = (int8_t)v;
-    }
-    __syncthreads();
-    // ---- deinterleave gather (ref :869-871) -----------------------------------------------
-    for (int i = lane; i < OPV_CODED; i += 64) {
-        const uint8_t v = s_q[deint_addr((uint32_t)i)];
-        s_d[i] = v;
-        if (td) td[i] = (int8_t)v;
+    // ---- quantise (ref :862-866: q=0 confident bit 0 ... q=7 confident bit 1) straight into the deinterleaved
+    // position (ref :869-871): value i of the decoder's input is symbol deint_addr(i) of the payload; a lane does the
+    // pair (2 t, 2 t + 1) of trellis step t
+    for (int t = lane; t < OPV_FBITS; t += 64) {
+        unsigned pair = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t i = 2u * (uint32_t)t + (uint32_t)h, a = deint_addr(i);
+            const double nrm = (-soft[(first + a) & mask] / scale) * 3.5 + 3.5;  // contraction is off for this TU
+            int v = (int)(nrm + 0.5);                                            // C truncation toward zero
+            v = v < 0 ? 0 : (v > 7 ? 7 : v);
+            pair |= (unsigned)v << (4 * h);
+            if (tq) tq[a] = (int8_t)v;
+            if (td) td[i] = (int8_t)v;
+        }
+        s_d[t] = (uint8_t)pair;
     }
     __syncthreads();
 
@@ -139,7 +146,6 @@ __device__ __forceinline__ void decode_one(const double* __restrict__ soft, uint
         m2c[ph] = __builtin_parity((unsigned)(f & 0x6D)) ? 7 : 0;
     }
     int metric = (lane == 0) ? 0 : 0x3FFFFFF0;                   // ref :805-806
-    const uint16_t* s_d2 = reinterpret_cast<const uint16_t*>(s_d);
     // The step's inputs and outputs are wave-uniform, and fetching / storing them one step at a time cost more
     // issue slots than the add-compare-select itself (an LDS read + wait + v_readfirstlane to get the symbol pair,
     // an exec-masked 64-bit LDS store by lane 0 for the decision word: 17 of 27 instructions per step). So the
@@ -156,8 +162,8 @@ __device__ __forceinline__ void decode_one(const double* __restrict__ soft, uint
         constexpr int SLOT = decltype(slot_tag)::value;
         constexpr int PH = SLOT % 6;                              // blocks start on a multiple of six steps
         constexpr int K = (5 - PH + 6) % 6;
-        const unsigned pair = (unsigned)__builtin_amdgcn_readlane(pairs, SLOT);   // sg1 | sg2<<8, wave-uniform
-        const int sg1 = (int)(pair & 0xFF), sg2 = (int)(pair >> 8);
+        const unsigned pair = (unsigned)__builtin_amdgcn_readlane(pairs, SLOT);   // sg1 | sg2 << 4, wave-uniform
+        const int sg1 = (int)(pair & 0xF), sg2 = (int)(pair >> 4);
         const int b1 = m1c[PH] ^ sg1, c = m2c[PH] ^ sg2;         // ref :823-824
         int mp;                                                   // metric held by lane ^ (1 << K)
         if constexpr (K == 0) mp = __builtin_amdgcn_mov_dpp(metric, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
@@ -192,13 +198,13 @@ __device__ __forceinline__ void decode_one(const double* __restrict__ soft, uint
     constexpr int kBlk = 48;
     static_assert(kBlk % 6 == 0 && OPV_FBITS % kBlk == 16, "22 full blocks and a tail of 16 steps (6 + 6 + 4)");
     for (int tb = 0; tb + kBlk <= OPV_FBITS; tb += kBlk) {
-        pairs = (int)s_d2[tb + (lane < kBlk ? lane : 0)];
+        pairs = (int)s_d[tb + (lane < kBlk ? lane : 0)];
         OPV_ACS6(0); OPV_ACS6(6); OPV_ACS6(12); OPV_ACS6(18); OPV_ACS6(24); OPV_ACS6(30); OPV_ACS6(36); OPV_ACS6(42);
         if (lane < kBlk) s_dec[tb + lane] = ((unsigned long long)(unsigned)dhi << 32) | (unsigned)dlo;
     }
     {
         constexpr int tb = OPV_FBITS - 16;
-        pairs = (int)s_d2[tb + (lane & 15)];
+        pairs = (int)s_d[tb + (lane & 15)];
         OPV_ACS6(0); OPV_ACS6(6);
         acs(std::integral_constant<int, 12>{}); acs(std::integral_constant<int, 13>{});
         acs(std::integral_constant<int, 14>{}); acs(std::integral_constant<int, 15>{});
@@ -216,49 +222,65 @@ __device__ __forceinline__ void decode_one(const double* __restrict__ soft, uint
         if (om < bm || (om == bm && os < bs)) { bm = om; bs = os; bl = ol; }
     }
 
-    // ---- traceback + pack + derandomise (ref :839-843, :878-895), uniform on all lanes ---------
-    // in lane space: the decoded bit is bit k of the current lane, the predecessor's lane has that bit
-    // replaced by the decision
-    int cur = bl;
-    // 24 steps are four turns of the bit position k and three output bytes: inside such a group every step's k is a
-    // compile-time constant (shifts by immediates, no scalar bookkeeping). The bytes go to LDS still randomised; the
-    // LFSR table is applied by all lanes at once on the way out (a per-byte constant-memory load inside this serial
-    // walk would put a global-memory round trip on every eighth step).
-    constexpr int kK0 = (5 - (OPV_FBITS - 1) % 6 + 6) % 6;
-    auto trace_byte = [&](auto first_step_tag, int i) {
-        constexpr int S0 = decltype(first_step_tag)::value;
-        unsigned byte = 0;
-        const int t0 = OPV_FBITS - 1 - 8 * i;
+    // ---- traceback + pack + derandomise (ref :839-843, :878-895) on the SCALAR unit ----------------
+    // in lane space: the decoded bit is bit k of the current lane, the predecessor's lane has that bit replaced by the
+    // decision. The walk is one chain of 1072 dependent steps, the same for every lane: as vector code (round 2: 8.7
+    // instructions per bit, a v_lshrrev_b64 by the current lane among them) it filled the SIMD's issue slots with 64
+    // copies of one number. Now the decision words come a block at a time (lane l <- word of step t_hi - l: one
+    // ds_read_b64 per 48 steps), each step takes its word by two v_readlane and does everything else in SGPRs - shift by
+    // the current lane, bit extract, three xors - which the scalar unit runs beside the other waves' vector work.
+    // Blocks are 48 steps (eight turns of the bit position k, six output bytes) so that every k is an immediate; the 16
+    // steps of 1072 = 16 + 22 x 48 go first. The bytes go to LDS still randomised; the LFSR table is applied by all lanes
+    // at once on the way out.
+    uint32_t cur = uni32((uint32_t)bl);
+    constexpr int kK0 = (5 - (OPV_FBITS - 1) % 6 + 6) % 6;       // bit position of the walk's first step (t = 1071)
+    auto trace_block = [&](auto nsteps_tag, auto k0_tag, int t_hi, int byte0) {
+        constexpr int NS = decltype(nsteps_tag)::value;          // steps of this block: t_hi, t_hi - 1, ...
+        constexpr int KB = decltype(k0_tag)::value;              // k of its first step
+        const unsigned long long mine = s_dec[t_hi - (lane < NS ? lane : 0)];
+        const int wlo = (int)(unsigned)mine, whi = (int)(unsigned)(mine >> 32);
+        unsigned long long acc = 0;                              // decoded bits in walk order: bit j of byte i is step 8 i + j
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = (kK0 + S0 + j) % 6;                     // k(t-1) = k(t) + 1 mod 6
-            const int t = t0 - j;
-            const unsigned b = (unsigned)(cur >> k) & 1u;         // bits[t] = s % 2 -> bit j of byte i
-            byte |= b << j;
-            if (tb && lane == 0) tb[t] = (uint8_t)b;
-            const unsigned d = (unsigned)((s_dec[t] >> cur) & 1ull);
-            cur ^= (int)((b ^ d) << k);
+        for (int j = 0; j < NS; ++j) {
+            const int k = (KB + j) % 6;                          // k(t-1) = k(t) + 1 mod 6
+            const unsigned long long word = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(whi, j) << 32) |
+                                            (unsigned)__builtin_amdgcn_readlane(wlo, j);
+            const uint32_t b = (cur >> k) & 1u;                  // bits[t] = s % 2
+            const uint32_t d = (uint32_t)(word >> cur) & 1u;
+            acc |= (unsigned long long)b << j;
+            if (tb) { if (lane == 0) tb[t_hi - j] = (uint8_t)b; }
+            cur ^= (b ^ d) << k;
         }
-        if (lane == 0) s_out[i] = (uint8_t)byte;
+        if (lane < NS / 8) s_out[byte0 + lane] = (uint8_t)(acc >> (8 * lane));
     };
-    static_assert(OPV_FB % 3 == 2, "44 groups of three bytes and a tail of two");
-    int i = 0;
-    for (; i + 3 <= OPV_FB; i += 3) {
-        trace_byte(std::integral_constant<int, 0>{}, i);
-        trace_byte(std::integral_constant<int, 8>{}, i + 1);
-        trace_byte(std::integral_constant<int, 16>{}, i + 2);
-    }
-    trace_byte(std::integral_constant<int, 0>{}, i);
-    trace_byte(std::integral_constant<int, 8>{}, i + 1);
+    static_assert(OPV_FBITS == 16 + 22 * 48, "a head of 16 steps (two bytes), then 22 blocks of 48 (six bytes each)");
+    trace_block(std::integral_constant<int, 16>{}, std::integral_constant<int, kK0>{}, OPV_FBITS - 1, 0);
+    for (int blk = 0; blk < 22; ++blk)
+        trace_block(std::integral_constant<int, 48>{}, std::integral_constant<int, (kK0 + 16) % 6>{}, OPV_FBITS - 17 - 48 * blk, 2 + 6 * blk);
     __syncthreads();
     for (int q = lane; q < OPV_FB; q += 64) out[q] = (uint8_t)(s_out[q] ^ kLfsr.b[q]);   // derandomise (ref :887-895)
     if (lane == 0) *metric_out = bm;
 }
 
-constexpr int kDecodeLds = 17152 + 144;
-static_assert(2 * OPV_CODED % 8 == 0 && 2 * OPV_CODED + 8 * OPV_FBITS <= 17152, "decision words fit behind s_q / s_d");
+constexpr int kDecodeLds = OPV_FBITS + 8 * OPV_FBITS + 144;      // 9 792 B: sixteen frames per CU = four waves per SIMD
+static_assert(OPV_FBITS % 8 == 0, "decision words are 8-byte aligned behind the 1072 value pairs");
+static_assert(16 * kDecodeLds <= 160 * 1024, "sixteen workgroups per CU");
 
 }  // namespace
+
+// Pre-pass, one FRAME per lane: scale of frames dec_from .. n_frames-1 of every stream into st.fscale (same flattening and
+// striding as k_frame_decode below: thread id -> stream id / per_stream, frames dec_from + id % per_stream, + per_stream, ...)
+extern "C" __global__ __launch_bounds__(64) void k_frame_scale(OpvStream* __restrict__ streams, uint32_t per_stream, uint32_t n_streams) {
+    const uint32_t id = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t sidx = id / per_stream;
+    if (sidx >= n_streams) return;
+    OpvStream& st = streams[sidx];
+    const uint32_t n_frames = st.n_frames;
+    for (uint32_t f = st.dec_from + id % per_stream; f < n_frames; f += per_stream) {
+        const uint32_t slot = f % st.cap_frames;
+        st.fscale[slot] = payload_scale(st.soft, (uint32_t)st.frec[slot].payload_sym, (uint32_t)(st.cap_soft - 1));
+    }
+}
 
 // grid = n_streams x (max new frames per stream), flattened (stream-major: a stream's frames are neighbours, so are
 // their soft symbols in L2); frames dec_from .. n_frames-1 of each stream
@@ -271,21 +293,26 @@ extern "C" __global__ __launch_bounds__(64) void k_frame_decode(OpvStream* __res
     for (uint32_t f = st.dec_from + blockIdx.x % per_stream; f < n_frames; f += per_stream) {
         const uint32_t slot = f % st.cap_frames;  // frame records / frames / metrics are rings
         const OpvFrameRec rec = st.frec[slot];
-        decode_one(st.soft, (uint32_t)rec.payload_sym, (uint32_t)(st.cap_soft - 1), st.frames + (size_t)slot * OPV_FB,
+        decode_one(st.soft, (uint32_t)rec.payload_sym, (uint32_t)(st.cap_soft - 1), st.fscale[slot], st.frames + (size_t)slot * OPV_FB,
                    st.metrics + slot, nullptr, nullptr, nullptr, lds);
         __syncthreads();                          // the next frame reuses this workgroup's LDS
     }
 }
 
-// stand-alone decoder over caller-provided payloads (parity tap / opv_decode_payloads)
+// stand-alone decoder over caller-provided payloads (parity tap / opv_decode_payloads): scales first, one payload per lane
+extern "C" __global__ __launch_bounds__(64) void k_payload_scale(const double* __restrict__ soft, uint32_t n, double* __restrict__ scales) {
+    const uint32_t f = blockIdx.x * 64u + threadIdx.x;
+    if (f < n) scales[f] = payload_scale(soft + (size_t)f * OPV_CODED, 0u, 0xFFFFFFFFu);
+}
 extern "C" __global__ __launch_bounds__(64) void k_decode_payloads(const double* __restrict__ soft, uint32_t n,
+                                                                    const double* __restrict__ scales,
                                                                     uint8_t* __restrict__ out,
                                                                     int32_t* __restrict__ metrics, int8_t* q,
                                                                     int8_t* deint, uint8_t* bits) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[kDecodeLds];
     const uint32_t f = blockIdx.x;
     if (f >= n) return;
-    decode_one(soft + (size_t)f * OPV_CODED, 0u, 0xFFFFFFFFu, out + (size_t)f * OPV_FB, metrics + f,
+    decode_one(soft + (size_t)f * OPV_CODED, 0u, 0xFFFFFFFFu, scales[f], out + (size_t)f * OPV_FB, metrics + f,
                q ? q + (size_t)f * OPV_CODED : nullptr, deint ? deint + (size_t)f * OPV_CODED : nullptr,
                bits ? bits + (size_t)f * OPV_FBITS : nullptr, lds);
 }

@@ -42,17 +42,22 @@ __device__ inline void advance(double& ph, double inc) {  // opv-mod.cpp:274-279
     while (ph < -kPi) ph += kTwoPi;
 }
 
-// the randomiser's byte sequence (opv-mod.cpp:97-113: state 0xFF, taps 7 6 4 2, reset per frame), one thread per byte:
-// byte i's first bit is produced in state step 8 i
-__device__ inline unsigned lfsr_byte(int i) {
-    unsigned st = 0xFF, v = 0;
-    for (int k = 0; k < 8 * i; ++k) st = ((st << 1) | (((st >> 7) ^ (st >> 6) ^ (st >> 4) ^ (st >> 2)) & 1u)) & 0xFFu;
-    for (int k = 0; k < 8; ++k) {
-        v = (v << 1) | ((st >> 7) & 1u);
-        st = ((st << 1) | (((st >> 7) ^ (st >> 6) ^ (st >> 4) ^ (st >> 2)) & 1u)) & 0xFFu;
+// the randomiser's byte sequence (opv-mod.cpp:97-113: state 0xFF, taps 7 6 4 2, reset per frame): a constant table
+struct LfsrTable { uint8_t b[OPV_FB]; };
+constexpr LfsrTable make_lfsr() {
+    LfsrTable t{};
+    unsigned st = 0xFF;
+    for (int i = 0; i < OPV_FB; ++i) {
+        unsigned v = 0;
+        for (int k = 0; k < 8; ++k) {
+            v = (v << 1) | ((st >> 7) & 1u);
+            st = ((st << 1) | (((st >> 7) ^ (st >> 6) ^ (st >> 4) ^ (st >> 2)) & 1u)) & 0xFFu;
+        }
+        t.b[i] = (uint8_t)v;
     }
-    return v;
+    return t;
 }
+__constant__ LfsrTable kTxLfsr = make_lfsr();
 }  // namespace
 
 // frames: [n_frames][134]; codes: [n_frames * 2168] (bit 0: symbol bit, bit 1: parity of the frame's bits before it);
@@ -68,7 +73,7 @@ extern "C" __global__ __launch_bounds__(256) void k_tx_encode(const uint8_t* __r
     const uint8_t* p = frames + (size_t)f * OPV_FB;
     if (tid < OPV_FB) {
         // byte 133 goes first, MSB first (opv-mod.cpp:186-196): input bit t = bit (7 - t % 8) of byte (133 - t / 8)
-        const unsigned v = p[tid] ^ lfsr_byte(tid);
+        const unsigned v = p[tid] ^ kTxLfsr.b[tid];
         const int t0 = 8 * (OPV_FB - 1 - tid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) u[t0 + b] = (uint8_t)((v >> (7 - b)) & 1u);

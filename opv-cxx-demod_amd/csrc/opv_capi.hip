@@ -27,8 +27,10 @@ extern "C" __global__ void k_msk_frontend_x4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_coherent_frontend(OpvStream*, double, double);
 extern "C" __global__ void k_sync_track(OpvStream*);
+extern "C" __global__ void k_frame_scale(OpvStream*, uint32_t, uint32_t);
 extern "C" __global__ void k_frame_decode(OpvStream*, uint32_t);
-extern "C" __global__ void k_decode_payloads(const double*, uint32_t, uint8_t*, int32_t*, int8_t*, int8_t*, uint8_t*);
+extern "C" __global__ void k_payload_scale(const double*, uint32_t, double*);
+extern "C" __global__ void k_decode_payloads(const double*, uint32_t, const double*, uint8_t*, int32_t*, int8_t*, int8_t*, uint8_t*);
 extern "C" __global__ void k_channel(const int4*, int4*, uint64_t, double, double, double, uint64_t);
 extern "C" __global__ void k_resample_clock(const int*, uint64_t, int*, uint64_t, double);
 extern "C" __global__ void k_tx_encode(const uint8_t*, uint32_t, uint8_t*, uint8_t*);
@@ -133,6 +135,7 @@ struct opv_ctx {
     double* d_chunks = nullptr;
     uint8_t* d_frames = nullptr;
     int32_t* d_metrics = nullptr;
+    double* d_fscale = nullptr;
     int32_t* d_counts = nullptr;
     double* d_offs_wtab = nullptr;      // k_offset_search's moment weights: [40 taps][cos, sin][OPV_OFFS_TERMS]
     uint64_t cap_soft = 0;
@@ -263,6 +266,7 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
     HIPCHK_C(hipMalloc(&c->d_chunks, sizeof(double) * 5 * c->cap_chunks * S));
     HIPCHK_C(hipMalloc(&c->d_frames, (size_t)OPV_FB * c->cap_frames * S));
     HIPCHK_C(hipMalloc(&c->d_metrics, sizeof(int32_t) * c->cap_frames * S));
+    HIPCHK_C(hipMalloc(&c->d_fscale, sizeof(double) * c->cap_frames * S));
     HIPCHK_C(hipMalloc(&c->d_counts, sizeof(int32_t) * S));
     {   // cos / sin(pi i / 80) x u^k / k!, u = i - 19.5: the tone tables of the offset search folded into its Taylor weights
         std::vector<double> w((size_t)OPV_SPS * 2 * OPV_OFFS_TERMS);
@@ -292,6 +296,7 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
         s.chunk_log = c->d_chunks + (size_t)5 * c->cap_chunks * i;
         s.frames = c->d_frames + (size_t)OPV_FB * c->cap_frames * i;
         s.metrics = c->d_metrics + (size_t)c->cap_frames * i;
+        s.fscale = c->d_fscale + (size_t)c->cap_frames * i;
         s.cap_frames = c->cap_frames;
         s.cap_events = c->cap_events;
         s.cap_chunks = c->cap_chunks;
@@ -326,7 +331,7 @@ extern "C" void opv_destroy(opv_ctx* c) {
     }
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_counts, c->d_tx_phases, c->d_offs_wtab, c->d_tx_ckpt, c->d_tx_frames, c->d_tx_codes, c->d_tx_fpar, c->d_tx_cnt, c->d_tx_list};
+    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_fscale, c->d_counts, c->d_tx_phases, c->d_offs_wtab, c->d_tx_ckpt, c->d_tx_frames, c->d_tx_codes, c->d_tx_fpar, c->d_tx_cnt, c->d_tx_list};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -509,6 +514,8 @@ extern "C" int opv_process(opv_ctx* c) {
     uint64_t fr = max_new / (uint64_t)(OPV_FSYMS * 38) + 4;
     if (fr > c->cap_frames) fr = c->cap_frames;
     if (fr * (uint64_t)S > 0x7FFFFFFFull) return fail(OPV_EINVAL, "opv_process: streams x frames per round exceeds the grid limit");
+    // the quantiser's scale (2144 dependent additions per frame) with one frame per lane, then one wave per frame
+    k_frame_scale<<<(unsigned)((fr * (uint64_t)S + 63) / 64), 64, 0, c->stream>>>(c->d_streams, (uint32_t)fr, (uint32_t)S);
     k_frame_decode<<<(unsigned)(fr * (uint64_t)S), 64, 0, c->stream>>>(c->d_streams, (uint32_t)fr);
     if (tm) { HIPCHK(hipEventRecord(c->ev[7], c->stream)); c->timing_valid = true; }
     k_collect_counts<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_counts, S);
@@ -766,18 +773,21 @@ extern "C" int opv_decode_payloads(opv_ctx* c, const double* soft, size_t n, uin
     int32_t* d_met = nullptr;
     int8_t *d_q = nullptr, *d_d = nullptr;
     uint8_t* d_b = nullptr;
+    double* d_scale = nullptr;
     int rc = OPV_OK;
     auto chk = [&](hipError_t e, const char* w) { if (e != hipSuccess && rc == OPV_OK) rc = fail(OPV_EHIP, w, e); };
     chk(hipMalloc(&d_soft, sizeof(double) * OPV_CODED * n), "hipMalloc soft");
     chk(hipMalloc(&d_out, (size_t)OPV_FB * n), "hipMalloc out");
     chk(hipMalloc(&d_met, sizeof(int32_t) * n), "hipMalloc metrics");
+    chk(hipMalloc(&d_scale, sizeof(double) * n), "hipMalloc scales");
     if (q) chk(hipMalloc(&d_q, (size_t)OPV_CODED * n), "hipMalloc q");
     if (deint) chk(hipMalloc(&d_d, (size_t)OPV_CODED * n), "hipMalloc deint");
     if (bits) chk(hipMalloc(&d_b, (size_t)OPV_FBITS * n), "hipMalloc bits");
     if (rc == OPV_OK) {
         chk(hipMemcpyAsync(d_soft, soft, sizeof(double) * OPV_CODED * n, hipMemcpyHostToDevice, c->stream), "H2D soft");
         chk(hipMemsetAsync(d_out, 0, (size_t)OPV_FB * n, c->stream), "memset");
-        k_decode_payloads<<<(unsigned)n, 64, 0, c->stream>>>(d_soft, (uint32_t)n, d_out, d_met, d_q, d_d, d_b);
+        k_payload_scale<<<(unsigned)((n + 63) / 64), 64, 0, c->stream>>>(d_soft, (uint32_t)n, d_scale);
+        k_decode_payloads<<<(unsigned)n, 64, 0, c->stream>>>(d_soft, (uint32_t)n, d_scale, d_out, d_met, d_q, d_d, d_b);
         chk(hipGetLastError(), "k_decode_payloads launch");
         chk(hipMemcpyAsync(out, d_out, (size_t)OPV_FB * n, hipMemcpyDeviceToHost, c->stream), "D2H out");
         chk(hipMemcpyAsync(metrics, d_met, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream), "D2H metrics");
@@ -786,7 +796,7 @@ extern "C" int opv_decode_payloads(opv_ctx* c, const double* soft, size_t n, uin
         if (bits) chk(hipMemcpyAsync(bits, d_b, (size_t)OPV_FBITS * n, hipMemcpyDeviceToHost, c->stream), "D2H bits");
         chk(hipStreamSynchronize(c->stream), "sync");
     }
-    void* ptrs[] = {d_soft, d_out, d_met, d_q, d_d, d_b};
+    void* ptrs[] = {d_soft, d_out, d_met, d_q, d_d, d_b, d_scale};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     return rc;
 }

@@ -50,6 +50,7 @@ struct OpvStream {
     double* chunk_log;   // 5 doubles per demodulate() call
     uint8_t* frames;     // [cap_frames][134]
     int32_t* metrics;    // [cap_frames]
+    double* fscale;      // [cap_frames] quantiser scale of each released frame (k_frame_scale -> k_frame_decode)
     uint32_t cap_frames, cap_events, cap_chunks, pad1;
 
     // ---- MSKDemodulatorAFC carry (ref :337-347) ----
