@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define OPV_ABI_VERSION 2
+#define OPV_ABI_VERSION 3
 
 #define OPV_SAMPLES_PER_SYMBOL 40    /* src/opv-demod.cpp:39  */
 #define OPV_FRAME_BYTES 134          /* :49  */
@@ -191,6 +191,26 @@ int opv_get_state(opv_ctx* ctx, int stream, opv_stream_state* out);
 int opv_device_frames(opv_ctx* ctx, const uint8_t** d_frames, const int32_t** d_metrics,
                       const int32_t** d_counts, size_t* frame_capacity);
 void* opv_hip_stream(opv_ctx* ctx);
+
+/* ---- multi-GPU (BASELINE configs[4]; no counterpart in the reference, whose streams are separate processes) -----------
+ * Streams shard contiguously over GPUs - one context per GPU, no data-path collective - and the decoded frames return to one
+ * rank with ONE gather: ncclGather (/opt/rocm/include/rccl/rccl.h:745) of every context's [n_streams][frame_capacity][134]
+ * frame buffer and [n_streams] counts, on the context's HIP stream behind the kernels of the last opv_process
+ * (asynchronous; opv_sync waits). d_frames_all / d_counts_all: DEVICE buffers on the root's GPU of world x that size, in
+ * rank = global stream order (ignored on other ranks). All contexts of a communicator must have the same n_streams and
+ * max_samples. `comm` is an ncclComm_t: the caller's own (a C++ host that links RCCL), or one made here - RCCL is bound with
+ * dlopen at first use, so that callers need no RCCL headers and single-GPU callers no RCCL at all:
+ *   one process per GPU:   rank 0: opv_comm_unique_id(id), hand the 128 bytes to the other ranks, everyone opv_comm_init,
+ *                          then opv_gather_frames once per round;
+ *   one process, N GPUs:   opv_comm_init_all(comms, N, devices) (rank i on devices[i]), then opv_gather_frames_all(ctxs, comms,
+ *                          N, ...) once per round: the N ranks' gathers issued by one thread inside one RCCL group. */
+int opv_comm_unique_id(char out128[128]);
+int opv_comm_init(void** comm, int world, int rank, const char id128[128], int device);
+int opv_comm_init_all(void** comms, int n_devices, const int* devices);
+void opv_comm_destroy(void* comm);
+int opv_gather_frames(opv_ctx* ctx, void* comm, int root, uint8_t* d_frames_all, int32_t* d_counts_all);
+int opv_gather_frames_all(opv_ctx* const* ctxs, void* const* comms, int n, int root, uint8_t* d_frames_all,
+                          int32_t* d_counts_all);
 
 /* ---- parity taps (debug): the intermediates the 1e-5 contract is checked on ------------ */
 /* soft symbols by absolute symbol index; only the retained tail of a long pushed stream is available */

@@ -4,6 +4,7 @@
 // four hot-path kernels on one HIP stream. There is NO CPU implementation of the hot path in
 // this library: without a usable HIP device opv_create fails with OPV_ENODEV.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <climits>
 #include <cmath>
@@ -918,4 +919,124 @@ extern "C" long opv_tx_modulate_device(opv_ctx* c, const uint8_t* frames, size_t
         }
     }
     return (long)n_amb;
+}
+
+
+// ---- multi-GPU: the one collective of the path (ncclGather, /opt/rocm/include/rccl/rccl.h:745) ---------------
+// RCCL is bound at first use (dlopen: a process that loaded PyTorch gets PyTorch's copy, a stand-alone C++ host the
+// system's), so a single-GPU caller never needs it. Prototypes restated from rccl.h; ncclUniqueId is 128 opaque bytes
+// passed by value.
+namespace {
+struct RcclId { char internal[128]; };
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(RcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Gather)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+Rccl& rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (x.lib) break;
+        }
+        if (!x.lib) return x;
+        auto sym = [&](const char* n) { return dlsym(x.lib, n); };
+        x.GetUniqueId = (int (*)(RcclId*))sym("ncclGetUniqueId");
+        x.CommInitRank = (int (*)(void**, int, RcclId, int))sym("ncclCommInitRank");
+        x.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+        x.Gather = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclGather");
+        x.GroupStart = (int (*)())sym("ncclGroupStart");
+        x.GroupEnd = (int (*)())sym("ncclGroupEnd");
+        x.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.Gather && x.GroupStart && x.GroupEnd;
+        return x;
+    }();
+    return r;
+}
+int rccl_fail(const char* what, int rc) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error");
+    g_err = buf;
+    return OPV_EHIP;
+}
+constexpr int kNcclUint8 = 1, kNcclInt32 = 2;   // ncclDataType_t (rccl.h:459-461)
+}  // namespace
+
+extern "C" int opv_comm_unique_id(char out128[128]) {
+    if (!out128) return fail(OPV_EINVAL, "null argument");
+    if (!rccl().ok) return fail(OPV_ENODEV, "librccl.so.1 could not be loaded (multi-GPU gather needs RCCL)");
+    RcclId id;
+    if (int rc = rccl().GetUniqueId(&id)) return rccl_fail("ncclGetUniqueId", rc);
+    std::memcpy(out128, id.internal, 128);
+    return OPV_OK;
+}
+
+extern "C" int opv_comm_init(void** comm, int world, int rank, const char id128[128], int device) {
+    if (!comm || !id128 || world < 1 || rank < 0 || rank >= world) return fail(OPV_EINVAL, "opv_comm_init: bad arguments");
+    if (!rccl().ok) return fail(OPV_ENODEV, "librccl.so.1 could not be loaded (multi-GPU gather needs RCCL)");
+    HIPCHK(hipSetDevice(device));
+    RcclId id;
+    std::memcpy(id.internal, id128, 128);
+    if (int rc = rccl().CommInitRank(comm, world, id, rank)) return rccl_fail("ncclCommInitRank", rc);
+    return OPV_OK;
+}
+
+extern "C" int opv_comm_init_all(void** comms, int n_devices, const int* devices) {
+    if (!comms || !devices || n_devices < 1) return fail(OPV_EINVAL, "opv_comm_init_all: bad arguments");
+    if (!rccl().ok) return fail(OPV_ENODEV, "librccl.so.1 could not be loaded (multi-GPU gather needs RCCL)");
+    RcclId id;
+    if (int rc = rccl().GetUniqueId(&id)) return rccl_fail("ncclGetUniqueId", rc);
+    if (int rc = rccl().GroupStart()) return rccl_fail("ncclGroupStart", rc);     // one thread, several devices: inits must be grouped
+    for (int i = 0; i < n_devices; ++i) {
+        HIPCHK(hipSetDevice(devices[i]));
+        if (int rc = rccl().CommInitRank(&comms[i], n_devices, id, i)) { (void)rccl().GroupEnd(); return rccl_fail("ncclCommInitRank", rc); }
+    }
+    if (int rc = rccl().GroupEnd()) return rccl_fail("ncclGroupEnd", rc);
+    return OPV_OK;
+}
+
+extern "C" void opv_comm_destroy(void* comm) {
+    if (comm && rccl().ok) (void)rccl().CommDestroy(comm);
+}
+
+// the gathers of ranks [0, n) that live in THIS thread (n = 1: one process per GPU), inside one RCCL group
+static int gather_group(opv_ctx* const* ctxs, void* const* comms, int n, int root, uint8_t* d_frames_all, int32_t* d_counts_all) {
+    if (!rccl().ok) return fail(OPV_ENODEV, "librccl.so.1 could not be loaded (multi-GPU gather needs RCCL)");
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || !comms[i]) return fail(OPV_EINVAL, "null context or communicator");
+        if (ctxs[i]->n_streams != ctxs[0]->n_streams || ctxs[i]->cap_frames != ctxs[0]->cap_frames)
+            return fail(OPV_EINVAL, "opv_gather_frames: every context must have the same n_streams and max_samples");
+    }
+    if (int rc = rccl().GroupStart()) return rccl_fail("ncclGroupStart", rc);
+    int rc = 0;
+    for (int i = 0; i < n && !rc; ++i) {
+        opv_ctx* c = ctxs[i];
+        if (hipSetDevice(c->cfg.device) != hipSuccess) { rc = -1; break; }
+        const size_t nb = (size_t)OPV_FB * c->cap_frames * (size_t)c->n_streams;
+        // on the context's stream: behind the kernels of its last opv_process
+        rc = rccl().Gather(c->d_frames, d_frames_all, nb, kNcclUint8, root, comms[i], c->stream);
+        if (!rc) rc = rccl().Gather(c->d_counts, d_counts_all, (size_t)c->n_streams, kNcclInt32, root, comms[i], c->stream);
+    }
+    const int rc2 = rccl().GroupEnd();
+    if (rc == -1) return fail(OPV_EHIP, "hipSetDevice failed");
+    if (rc) return rccl_fail("ncclGather", rc);
+    if (rc2) return rccl_fail("ncclGroupEnd", rc2);
+    return OPV_OK;
+}
+
+extern "C" int opv_gather_frames(opv_ctx* c, void* comm, int root, uint8_t* d_frames_all, int32_t* d_counts_all) {
+    return gather_group(&c, &comm, 1, root, d_frames_all, d_counts_all);
+}
+
+extern "C" int opv_gather_frames_all(opv_ctx* const* ctxs, void* const* comms, int n, int root, uint8_t* d_frames_all,
+                                     int32_t* d_counts_all) {
+    if (!ctxs || !comms || n < 1) return fail(OPV_EINVAL, "opv_gather_frames_all: bad arguments");
+    return gather_group(ctxs, comms, n, root, d_frames_all, d_counts_all);
 }

@@ -9,7 +9,11 @@
 // one-frame latency (a frame is released once 50 samples of the next one have arrived,
 // src/opv-demod.cpp:221) is unchanged.
 //
-//   opv-rx-bridge [-H host] [-P base_port] [-o hz] [-a alpha] [--device n] [-q] [input ...]
+//   opv-rx-bridge [-H host] [-P base_port] [-o hz] [-a alpha] [--device n | --devices a,b,...] [--gather] [-q] [input ...]
+//     --devices a,b,...  one context per listed GPU, the inputs sharded contiguously over them (stream k -> entry
+//                        k / ceil(S / N) of the list; BASELINE configs[4]'s layout in one C++ process); UDP output unchanged
+//     --gather           at the end, the decoded-frame buffers and counts of every context are gathered to the first
+//                        listed GPU with ONE RCCL gather (opv_gather_frames_all, ncclGather) and compared with what was sent
 //     inputs, one stream each ("N stdin/UDP sources"):
 //       PATH      file or FIFO with int16 I/Q
 //       -         stdin (also the only stream when no input is named, like `opv-modem -R`)
@@ -28,6 +32,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>   // the gather's receive buffers are this host's own device memory
 
 #include "../../include/opv_demod.h"
 
@@ -48,6 +54,8 @@ int main(int argc, char** argv) {
     bool quiet = false, have_off = false;
     double off = 0.0, afc = 0.001;
     int device = 0;
+    std::vector<int> devices;
+    bool gather = false;
     std::vector<std::string> paths;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "-H") && i + 1 < argc) host = argv[++i];
@@ -55,9 +63,12 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "-o") && i + 1 < argc) { off = atof(argv[++i]); have_off = true; }
         else if (!strcmp(argv[i], "-a") && i + 1 < argc) afc = atof(argv[++i]);
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--devices") && i + 1 < argc) {
+            for (const char* p = argv[++i]; *p;) { devices.push_back((int)strtol(p, (char**)&p, 10)); if (*p == ',') ++p; }
+        } else if (!strcmp(argv[i], "--gather")) gather = true;
         else if (!strcmp(argv[i], "-q")) quiet = true;
         else if (!strcmp(argv[i], "-h")) {
-            fprintf(stderr, "Usage: %s [-H host] [-P base_port] [-o hz] [-a alpha] [--device n] [-q] [input ...]\n", argv[0]);
+            fprintf(stderr, "Usage: %s [-H host] [-P base_port] [-o hz] [-a alpha] [--device n | --devices a,b,...] [--gather] [-q] [input ...]\n", argv[0]);
             return 0;
         } else paths.push_back(argv[i]);
     }
@@ -90,34 +101,46 @@ int main(int argc, char** argv) {
         if (inet_pton(AF_INET, host.c_str(), &dst[k].sin_addr) != 1) { fprintf(stderr, "bad host %s\n", host.c_str()); return 2; }
     }
 
+    // streams shard contiguously over the listed GPUs: global stream k is stream k % per of context k / per
+    if (devices.empty()) devices.push_back(device);
+    const int D = (int)devices.size(), per = (S + D - 1) / D;
     opv_cfg cfg{};
     cfg.streaming = 1;
     cfg.have_init_offset = have_off;
     cfg.init_offset_hz = off;
     cfg.afc_alpha = afc;
-    cfg.device = device;
     cfg.pll_bw_hz = 50.0;
     cfg.max_samples = 8 * OPV_CHUNK_SAMPLES;  // staging buffer per stream; streams themselves are unbounded
-    opv_ctx* ctx = nullptr;
-    if (opv_create(&ctx, S, &cfg) < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
-    if (!quiet) fprintf(stderr, "opv-rx-bridge: %d stream(s) -> udp://%s:%d..%d\n", S, host.c_str(), base_port, base_port + S - 1);
+    std::vector<opv_ctx*> ctxs(D, nullptr);
+    for (int d = 0; d < D; ++d) {
+        cfg.device = devices[d];
+        if (opv_create(&ctxs[d], per, &cfg) < 0) { fprintf(stderr, "opv-rx-bridge: device %d: %s\n", devices[d], opv_last_error()); return 2; }
+    }
+    if (!quiet) {
+        fprintf(stderr, "opv-rx-bridge: %d stream(s) -> udp://%s:%d..%d", S, host.c_str(), base_port, base_port + S - 1);
+        if (D > 1) fprintf(stderr, ", %d per context on %d contexts (GPUs", per, D);
+        for (int d = 0; D > 1 && d < D; ++d) fprintf(stderr, "%s%d", d ? "," : " ", devices[d]);
+        fprintf(stderr, D > 1 ? ")\n" : "\n");
+    }
 
     std::vector<pollfd> pfd(S);
     constexpr size_t kRead = 16384;                       // opv-modem's read size (src/opv-modem.cpp:734,753)
     constexpr size_t kDgram = 65536;                      // a UDP datagram is taken whole (<= 65507 bytes of payload)
     constexpr size_t kRound = 1u << 20;                   // at most this much per stream and poll round (0.12 s of IQ)
     std::vector<unsigned char> bufs((size_t)S * (kRound + kDgram + 4));   // one buffer per stream: a poll round is ONE batched push
-    std::vector<int> ids, pending_flush;
-    std::vector<const int16_t*> ptrs;
-    std::vector<size_t> lens;
+    std::vector<int> pending_flush;
+    std::vector<std::vector<int>> ids(D);
+    std::vector<std::vector<const int16_t*>> ptrs(D);
+    std::vector<std::vector<size_t>> lens(D);
     uint8_t frames[64 * OPV_FRAME_BYTES];
     opv_frame_meta meta[64];
     int open_streams = S;
     auto drain = [&]() -> int {
-        if (opv_process(ctx) < 0) return -1;
+        for (int d = 0; d < D; ++d)
+            if (opv_process(ctxs[d]) < 0) return -1;          // asynchronous: every GPU works while the first one is popped
         for (int k = 0; k < S; ++k) {
             for (;;) {
-                const long n = opv_pop_frames(ctx, k, frames, 64, meta);
+                const long n = opv_pop_frames(ctxs[k / per], k % per, frames, 64, meta);
                 if (n < 0) return -1;
                 for (long f = 0; f < n; ++f) {
                     sendto(sock, frames + f * OPV_FRAME_BYTES, OPV_FRAME_BYTES, 0, (sockaddr*)&dst[k], sizeof dst[k]);
@@ -133,7 +156,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < S; ++k) { pfd[k].fd = in[k].eof ? -1 : in[k].fd; pfd[k].events = POLLIN; pfd[k].revents = 0; }
         if (poll(pfd.data(), S, 10) < 0) break;  // 10 ms like the reference's select timeout
         bool any = false;
-        ids.clear(); ptrs.clear(); lens.clear();
+        for (int d = 0; d < D; ++d) { ids[d].clear(); ptrs[d].clear(); lens[d].clear(); }
         for (int k = 0; k < S; ++k) {
             if (in[k].eof) continue;
             if (!(pfd[k].revents & (POLLIN | POLLHUP))) continue;
@@ -150,7 +173,7 @@ int main(int argc, char** argv) {
                 have += (size_t)r;
             }
             const size_t ns = have / 4;
-            if (ns) { ids.push_back(k); ptrs.push_back(reinterpret_cast<const int16_t*>(buf)); lens.push_back(ns); any = true; }
+            if (ns) { ids[k / per].push_back(k % per); ptrs[k / per].push_back(reinterpret_cast<const int16_t*>(buf)); lens[k / per].push_back(ns); any = true; }
             in[k].samples += ns;
             in[k].ncarry = have - ns * 4;
             memcpy(in[k].carry, buf + ns * 4, in[k].ncarry);
@@ -161,12 +184,13 @@ int main(int argc, char** argv) {
                 any = true;
             }
         }
-        if (!ids.empty() && opv_push_iq_batch(ctx, (int)ids.size(), ids.data(), ptrs.data(), lens.data()) < 0) {
-            fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error());
-            return 2;
-        }
+        for (int d = 0; d < D; ++d)
+            if (!ids[d].empty() && opv_push_iq_batch(ctxs[d], (int)ids[d].size(), ids[d].data(), ptrs[d].data(), lens[d].data()) < 0) {
+                fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error());
+                return 2;
+            }
         for (int k : pending_flush)
-            if (opv_flush(ctx, k) < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
+            if (opv_flush(ctxs[k / per], k % per) < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
         pending_flush.clear();
         if (any && drain() < 0) { fprintf(stderr, "opv-rx-bridge: %s\n", opv_last_error()); return 2; }
     }
@@ -178,7 +202,7 @@ int main(int argc, char** argv) {
         *stalled = false;
         for (int k = 0; k < S; ++k) {
             opv_stream_state st;
-            if (opv_get_state(ctx, k, &st) < 0) continue;
+            if (opv_get_state(ctxs[k / per], k % per, &st) < 0) continue;
             *stalled |= st.stalled != 0;
             p += st.total_symbols + (uint64_t)st.frames_released + (uint64_t)in[k].frames;
         }
@@ -198,7 +222,40 @@ int main(int argc, char** argv) {
             fprintf(stderr, "stream %d: %.3f s of IQ, %ld frames (%ld perfect) -> port %d\n", k, in[k].samples / 2168000.0,
                     in[k].frames, in[k].perfect, base_port + k);
     }
-    opv_destroy(ctx);
+    int rc = total > 0 ? 0 : 1;
+    if (gather) {
+        // BASELINE configs[4]'s collective from a C++ host: every context's [per][cap][134] frame buffer + [per] counts to the
+        // first listed GPU with one RCCL gather (grouped over the contexts this thread owns), then a look at what arrived
+        size_t cap = 0;
+        const int32_t* d_counts0 = nullptr;
+        opv_device_frames(ctxs[0], nullptr, nullptr, &d_counts0, &cap);
+        std::vector<void*> comms(D, nullptr);
+        uint8_t* d_all = nullptr;
+        int32_t* d_cnt = nullptr;
+        const size_t nb = (size_t)per * cap * OPV_FRAME_BYTES;
+        bool ok = opv_comm_init_all(comms.data(), D, devices.data()) == 0;
+        if (!ok) fprintf(stderr, "opv-rx-bridge: gather: %s\n", opv_last_error());
+        ok = ok && hipSetDevice(devices[0]) == hipSuccess && hipMalloc((void**)&d_all, nb * D) == hipSuccess &&
+             hipMalloc((void**)&d_cnt, sizeof(int32_t) * per * D) == hipSuccess;
+        if (ok && opv_gather_frames_all(ctxs.data(), comms.data(), D, 0, d_all, d_cnt) < 0) { fprintf(stderr, "opv-rx-bridge: gather: %s\n", opv_last_error()); ok = false; }
+        for (int d = 0; ok && d < D; ++d) ok = opv_sync(ctxs[d]) == 0;
+        std::vector<int32_t> cnt((size_t)per * D);
+        ok = ok && hipMemcpy(cnt.data(), d_cnt, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost) == hipSuccess;
+        long gathered = 0, mismatch = 0;
+        for (int k = 0; ok && k < S; ++k) {
+            opv_stream_state st;
+            opv_get_state(ctxs[k / per], k % per, &st);
+            gathered += cnt[k];                                // rank-major = global stream order
+            mismatch += cnt[k] != st.frames_released;
+        }
+        if (ok) fprintf(stderr, "gather: %d rank(s) x %d stream(s) -> GPU %d over RCCL: %ld frames released in all, %ld stream(s) differ from the local counts\n",
+                        D, per, devices[0], gathered, mismatch);
+        if (!ok || mismatch) rc = 2;
+        if (d_all) (void)hipFree(d_all);
+        if (d_cnt) (void)hipFree(d_cnt);
+        for (void* c : comms) opv_comm_destroy(c);
+    }
+    for (opv_ctx* c : ctxs) opv_destroy(c);
     close(sock);
-    return total > 0 ? 0 : 1;
+    return rc;
 }

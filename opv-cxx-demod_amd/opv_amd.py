@@ -30,7 +30,8 @@ SAMPLE_RATE = 2168000.0
 EXPORTS = [
     "opv_create", "opv_destroy", "opv_last_error", "opv_abi_version", "opv_push_iq", "opv_push_iq_batch", "opv_flush",
     "opv_attach_device_iq", "opv_process", "opv_sync", "opv_set_frontend", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
-    "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_tap_soft", "opv_tap_chunks",
+    "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_comm_unique_id", "opv_comm_init", "opv_comm_init_all",
+    "opv_comm_destroy", "opv_gather_frames", "opv_gather_frames_all", "opv_tap_soft", "opv_tap_chunks",
     "opv_tap_offset_energies", "opv_tap_wave_info", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_bert_frames", "opv_tx_modulated_samples",
     "opv_tx_modulate", "opv_tap_tx_checkpoints", "opv_frontend_kernel", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device",
 ]
@@ -113,6 +114,13 @@ def lib():
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         L.opv_hip_stream.restype = C.c_void_p
         L.opv_hip_stream.argtypes = [C.c_void_p]
+        L.opv_comm_unique_id.argtypes = [C.c_char_p]
+        L.opv_comm_init.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.opv_comm_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
+        L.opv_comm_destroy.restype = None
+        L.opv_comm_destroy.argtypes = [C.c_void_p]
+        L.opv_gather_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.opv_gather_frames_all.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.opv_tap_soft.restype = C.c_long
         L.opv_tap_soft.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_size_t]
         L.opv_tap_chunks.restype = C.c_long
@@ -147,6 +155,21 @@ def _chk(rc):
     if rc < 0:
         raise OpvError(f"opv error {rc}: {lib().opv_last_error().decode()}")
     return rc
+
+
+def comm_create(world, rank, device=0, uid=None):
+    """RCCL communicator through the library's own binding (opv_comm_unique_id / opv_comm_init); returns (comm, uid)"""
+    if uid is None:
+        buf = C.create_string_buffer(128)
+        _chk(lib().opv_comm_unique_id(buf))
+        uid = buf.raw
+    comm = C.c_void_p()
+    _chk(lib().opv_comm_init(C.byref(comm), world, rank, uid, device))
+    return comm, uid
+
+
+def comm_destroy(comm):
+    lib().opv_comm_destroy(comm)
 
 
 # ---------------------------------------------------------------- transmit side (host)
@@ -303,6 +326,10 @@ class Demod:
 
     def hip_stream(self):
         return lib().opv_hip_stream(self.h)
+
+    def gather_frames(self, comm, root, d_frames_all, d_counts_all):
+        """opv_gather_frames: this context's frame buffer + counts to `root` over the RCCL communicator `comm`"""
+        _chk(lib().opv_gather_frames(self.h, comm, root, C.c_void_p(d_frames_all), C.c_void_p(d_counts_all)))
 
     def modulate_device(self, frames, d_out):
         """TX chain into HBM (bit-identical to modulate()); returns samples re-evaluated on the host."""

@@ -176,6 +176,41 @@ def test_gather_frames_under_nccl_world_1():
     assert ok is True and backend == "nccl" and nfr >= 8 * 5
 
 
+def test_c_side_gather_frames_world_1():
+    """include/opv_demod.h: opv_comm_unique_id + opv_comm_init + opv_gather_frames - the C ABI's own RCCL gather (ncclGather on
+    the context's stream, RCCL bound by dlopen: here PyTorch's copy, already in the process) at world 1 on a real 6-stream
+    run: the gathered [1][S][cap][134] frames and [1][S] counts equal the library's buffers, and every stream's frames the
+    oracle's. (The same call from a stand-alone C++ process: test_rx_bridge_shards_over_contexts_and_gathers_in_cxx.)"""
+    import torch
+    from __graft_entry__ import load_opv_amd, load_pkg_module
+    from oracle_lib import Oracle
+    amd, workload = load_opv_amd(), load_pkg_module("workload")
+    dev = torch.device("cuda", 0)
+    S, F = 6, 5
+    n = amd.lib().opv_tx_modulated_samples(F)
+    dm = amd.Demod(S, max_samples=n + 64, streaming=True)
+    d_iq, tx, n = workload.generate(amd, dm, torch, dev, range(100, 100 + S), F, 16.0)
+    for k in range(S):
+        dm.attach(k, d_iq[k].data_ptr(), n, eof=True)
+    dm.process()
+    fv, cv = workload.frame_views(dm, torch, dev)
+    comm, uid = amd.comm_create(1, 0, device=0)
+    assert len(uid) == 128
+    fa = torch.full((1,) + tuple(fv.shape), 0xEE, dtype=torch.uint8, device=dev)
+    ca = torch.full((1, S), -7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    dm.gather_frames(comm, 0, fa.data_ptr(), ca.data_ptr())        # asynchronous, behind the kernels on the context's stream
+    dm.sync()
+    assert bool(torch.equal(fa[0], fv)) and bool(torch.equal(ca[0], cv))
+    o = Oracle()
+    host = d_iq.cpu().numpy()
+    for k in range(S):
+        e = o.receive(host[k], streaming=True, want_soft=False)
+        assert int(ca[0, k]) == len(e["frames"]) and np.array_equal(fa[0, k, :len(e["frames"])].cpu().numpy(), e["frames"]), k
+    amd.comm_destroy(comm)
+    dm.close()
+
+
 def test_512_stream_context_vs_oracle():
     """configs[4]'s stream count in one context: 512 streams (8 shards of 64, global ids 0..511) x 3 frames,
     Eb/N0 16 dB, every stream against the oracle (frames, metrics, sync positions, tracker lines, offset estimate)."""

@@ -795,6 +795,63 @@ def test_rx_bridge_multi_stream_udp(amd, oracle, tmp_path):
         socks[k].close()
 
 
+def test_rx_bridge_shards_over_contexts_and_gathers_in_cxx(amd, oracle, tmp_path):
+    """The C++ side of BASELINE configs[4] (north_star: "Host code stays C++ ... RCCL ... only to gather decoded frames"):
+    `opv-rx-bridge --devices a,b` shards its inputs contiguously over one context per listed GPU (stream k -> context
+    k / ceil(S / N)); on this one-GPU box the list is 0,0 - two independent contexts on the same device - and five inputs
+    land 3 + 2. Every stream's datagrams must be the oracle's frames. `--devices 0 --gather` then runs the path's one
+    collective from the stand-alone C++ process: opv_comm_init_all + opv_gather_frames_all (ncclGather through the
+    SYSTEM's librccl, bound by dlopen), world 1 here, and checks the gathered counts against the local ones."""
+    import socket
+    import subprocess
+    base = 42000 + (os.getpid() % 1500) * 5
+    S = 5
+    socks = []
+    for k in range(S):
+        so = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        so.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1 << 22)
+        so.bind(("127.0.0.1", base + k))
+        so.setblocking(False)
+        socks.append(so)
+    caps, exps = [], []
+    for k in range(S):
+        x = oracle.modulate(oracle.bert_frames(6 + 2 * k, f"D{k}", 0xBBAADD, 9 * k))
+        if k % 2:
+            x = impair(x, amp=3000.0, f0_hz=-500.0 + 300.0 * k, ebn0_db=15.0, seed=10 + k)
+        f = tmp_path / f"d{k}.iq"
+        x.tofile(f)
+        caps.append(str(f))
+        exps.append(oracle.receive(x, streaming=True)["frames"])
+    exe = str(amd.PKG / "bin" / "opv-rx-bridge")
+
+    def collect():
+        out = []
+        for k in range(S):
+            got = []
+            while True:
+                try:
+                    got.append(socks[k].recv(2048))
+                except BlockingIOError:
+                    break
+            out.append(np.frombuffer(b"".join(got), np.uint8).reshape(-1, FRAME_BYTES))
+        return out
+
+    r = subprocess.run([exe, "-P", str(base), "--devices", "0,0"] + caps, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"3 per context on 2 contexts" in r.stderr, r.stderr.decode()
+    for k, got in enumerate(collect()):
+        assert np.array_equal(got, exps[k]), f"--devices 0,0 stream {k}: {len(got)} datagrams vs {len(exps[k])} frames"
+    r = subprocess.run([exe, "-P", str(base), "--devices", "0", "--gather"] + caps, capture_output=True, timeout=300)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err
+    total = sum(len(e) for e in exps)
+    assert f"gather: 1 rank(s) x {S} stream(s) -> GPU 0 over RCCL: {total} frames released in all, 0 stream(s) differ" in err, err
+    for k, got in enumerate(collect()):
+        assert np.array_equal(got, exps[k]), k
+    for so in socks:
+        so.close()
+
+
 def test_rx_bridge_udp_and_stdin_sources(amd, oracle, tmp_path):
     """SURVEY.md §8f row 3, the source side: one stream from stdin ('-'), one from UDP datagrams (udp:PORT, ended by
     an empty datagram), one from a file - the three in one GPU context; every stream's output datagrams are the
