@@ -930,11 +930,15 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 // the divisor's guard against digital silence: sum + 1e-100 IS sum unless sum is 0 (a non-zero sum of
                 // products of window sums is far above 1e-84), and an add needs no canonicalised operand where fmax does
                 dm_ = sum + kc_tiny;
-                // The silence test's compare HERE, its branch 35 instructions later: a v_cmp whose mask a scalar branch reads in
-                // the next instruction costs the lone wave a VALU -> SALU round trip (measured: 798 -> 776 cycles per symbol
-                // although this form issues one instruction more, an s_cmp on the mask)
-                zmask = __builtin_amdgcn_fcmp(sum, 0.0, 1 /*FCMP_OEQ*/);
-                asm volatile("" : "+s"(zmask));
+                // One wave per workgroup (WPB == 1): the silence test's compare HERE, its branch 35 instructions later - a v_cmp
+                // whose mask a scalar branch reads in the next instruction costs a lone wave a VALU -> SALU round trip (798 ->
+                // 774 cycles per symbol on clean 60-frame streams, 779 -> 774 on the bench workload, although this form issues
+                // one instruction more, an s_cmp on the mask). Four waves per workgroup keep the adjacent pair: with the CU's
+                // other three SIMDs busy the early form measured 850 cycles per symbol against 804 (1024 streams).
+                if constexpr (WPB == 1) {
+                    zmask = __builtin_amdgcn_fcmp(sum, 0.0, 1 /*FCMP_OEQ*/);
+                    asm volatile("" : "+s"(zmask));
+                }
             } else {
                 ee = row_bcast<2>(sq, seln); el = row_bcast<3>(shv, seln);
             }
@@ -994,7 +998,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 pd = fma(pd, h, c01.x);
                 pd = fma(sx, pd, pd_off);
                 pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));  // sign of cy
-                if (__builtin_expect(zmask != 0ull, 0)) {           // digital silence on either side (sum == 0, compared above)
+                if (__builtin_expect(WPB == 1 ? zmask != 0ull : uni_eq(sum, 0.0), 0)) {   // digital silence on either side
                     const double dr = fma(sg, P2o, P1o), di = fma(-sg, P4o, P3o);
                     const double2 sp = silence_pd(dr, di, prv, soft < 0.0, fo_sum, n_soft + (((my_soft_off - soft_off0) & soft_bmask) >> 3),
                                                   P1o, P2o, P3o, P4o);
