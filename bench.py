@@ -188,10 +188,9 @@ def main():
     mine = sharding.stream_range(rank, world, world * S)
     n = amd.lib().opv_tx_modulated_samples(F)
     dm = amd.Demod(S, max_samples=n + 64, streaming=True, device=local_rank)
-    t0 = time.perf_counter()
-    d_iq, tx_all, n = workload.generate(amd, dm, torch, dev, mine, F, args.ebn0)
-    torch.cuda.synchronize()
-    t_mod = time.perf_counter() - t0
+    gen_t = {}
+    d_iq, tx_all, n = workload.generate(amd, dm, torch, dev, mine, F, args.ebn0, timing=gen_t)
+    t_mod = gen_t["generate_s"]                          # BERT frames + device transmit chain + channel tool, all streams (allocation excluded)
     tx_frames = amd.bert_frames(F)                       # configs[1] / CPU-baseline capture (W5NYV)
 
     frames_view, counts_view = workload.frame_views(dm, torch, dev)
@@ -390,7 +389,7 @@ def main():
         one.close()
         # throughput-bound regime: many short streams carved out of the resident captures
         sweep = {}
-        for ns, nfr in ((256, 240), (512, 120), (1024, 60), (2048, 30), (4096, 15), (8192, 7)):
+        for ns, nfr in ((128, 480), (192, 320), (256, 240), (512, 120), (1024, 60), (2048, 30), (4096, 15), (8192, 7)):
             if nfr > F:
                 continue
             per = F // nfr

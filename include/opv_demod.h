@@ -250,6 +250,9 @@ size_t opv_tx_modulate(const uint8_t* frames134, size_t n_frames, int16_t* iq_ou
  * whose truncation could differ between device sincos and libm are re-evaluated on the host. Returns the number of samples so
  * patched (>= 0, normally 0) or a negative error. Synchronous. */
 long opv_tx_modulate_device(opv_ctx* ctx, const uint8_t* frames134, size_t n_frames, int16_t* d_iq_out);
+/* The same chain for a host that wants the samples back (`opv-mod -G`): a temporary device buffer, then D2H into iq_out
+ * (host, opv_tx_modulated_samples(n_frames) samples). */
+long opv_tx_modulate_device_to_host(opv_ctx* ctx, const uint8_t* frames134, size_t n_frames, int16_t* iq_out);
 /* Parity tap: entries [first, first + count) of the NCO checkpoint sequence the device transmit chain starts from - (ph1, ph2)
  * of src/opv-mod.cpp:274-279 at symbol 128 * entry of a run - from the build-time table, beyond it (4096 frames) from the host
  * continuation. Host only, needs no device. */

@@ -922,6 +922,18 @@ extern "C" long opv_tx_modulate_device(opv_ctx* c, const uint8_t* frames, size_t
 }
 
 
+extern "C" long opv_tx_modulate_device_to_host(opv_ctx* c, const uint8_t* frames, size_t n_frames, int16_t* iq_out) {
+    if (!c || !iq_out) return fail(OPV_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const size_t n = (n_frames * OPV_FSYMS + 100) * (size_t)OPV_SPS;
+    int16_t* d = nullptr;
+    HIPCHK(hipMalloc(&d, n * 4));
+    long rc = opv_tx_modulate_device(c, frames, n_frames, d);
+    if (rc >= 0 && hipMemcpy(iq_out, d, n * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(OPV_EHIP, "D2H of the modulated samples");
+    (void)hipFree(d);
+    return rc;
+}
+
 // ---- multi-GPU: the one collective of the path (ncclGather, /opt/rocm/include/rccl/rccl.h:745) ---------------
 // RCCL is bound at first use (dlopen: a process that loaded PyTorch gets PyTorch's copy, a stand-alone C++ host the
 // system's), so a single-GPU caller never needs it. Prototypes restated from rccl.h; ncclUniqueId is 128 opaque bytes

@@ -1,7 +1,8 @@
 // opv_mod_main.cpp — host signal source with the CLI of the reference `opv-mod`
 // (reference src/opv-mod.cpp:393-533): -S CALLSIGN -B N (BERT), -R (134-byte frames on
 // stdin), -t TOKEN; int16 I/Q on stdout. Thin wrapper over opv_tx_* (csrc/opv_tx.cpp),
-// whose output is sha256-identical to the reference modulator.
+// whose output is sha256-identical to the reference modulator. -G <n>: the whole chain on GPU n
+// (csrc/k_tx_modulate.hip, opv_tx_modulate_device_to_host) - the same bytes.
 #include <unistd.h>
 
 #include <cstdint>
@@ -17,7 +18,8 @@ static int usage(const char* prog) {  // ref opv-mod.cpp:393-412
     fprintf(stderr, "Usage: %s [OPTIONS]\n\n  -B FRAMES     BERT mode: generate N test frames\n"
                     "  -R            Raw mode: read 134-byte frames from stdin\n"
                     "  -S CALLSIGN   Station callsign (required for BERT mode)\n"
-                    "  -t TOKEN      24-bit token (default: 0xBBAADD)\n\n"
+                    "  -t TOKEN      24-bit token (default: 0xBBAADD)\n"
+                    "  -G DEVICE     run the transmit chain on that GPU (same output)\n\n"
                     "Output: 16-bit I/Q samples (little-endian, interleaved) to stdout\n", prog);
     return 1;
 }
@@ -27,13 +29,14 @@ int main(int argc, char** argv) {
     int bert = 0;
     bool raw = false;
     uint32_t token = 0xBBAADD;
-    int opt;
-    while ((opt = getopt(argc, argv, "S:B:t:Rcvh")) != -1) {
+    int opt, gpu = -1;
+    while ((opt = getopt(argc, argv, "S:B:t:G:Rcvh")) != -1) {
         switch (opt) {
             case 'S': call = optarg; break;
             case 'B': bert = atoi(optarg); break;
             case 't': token = (uint32_t)strtoul(optarg, nullptr, 0); break;
             case 'R': raw = true; break;
+            case 'G': gpu = atoi(optarg); break;
             case 'c': case 'v': break;  // continuous/verbose: not needed by any caller of the hot path
             default: return usage(argv[0]);
         }
@@ -59,7 +62,21 @@ int main(int argc, char** argv) {
     }
     const size_t nf = frames.size() / OPV_FRAME_BYTES;
     std::vector<int16_t> iq(2 * opv_tx_modulated_samples(nf));
-    opv_tx_modulate(frames.data(), nf, iq.data());
+    if (gpu >= 0) {
+        opv_cfg cfg{};
+        cfg.streaming = 1;
+        cfg.afc_alpha = 0.001;
+        cfg.device = gpu;
+        cfg.max_samples = 1 << 16;                 // (the context is only the device handle of the transmit chain here)
+        opv_ctx* ctx = nullptr;
+        if (opv_create(&ctx, 1, &cfg) < 0 || opv_tx_modulate_device_to_host(ctx, frames.data(), nf, iq.data()) < 0) {
+            fprintf(stderr, "opv-mod: %s\n", opv_last_error());
+            return 2;
+        }
+        opv_destroy(ctx);
+    } else {
+        opv_tx_modulate(frames.data(), nf, iq.data());
+    }
     const char* p = reinterpret_cast<const char*>(iq.data());
     size_t left = iq.size() * sizeof(int16_t);
     while (left) {

@@ -33,7 +33,7 @@ EXPORTS = [
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_comm_unique_id", "opv_comm_init", "opv_comm_init_all",
     "opv_comm_destroy", "opv_gather_frames", "opv_gather_frames_all", "opv_tap_soft", "opv_tap_chunks",
     "opv_tap_offset_energies", "opv_tap_wave_info", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_bert_frames", "opv_tx_modulated_samples",
-    "opv_tx_modulate", "opv_tap_tx_checkpoints", "opv_frontend_kernel", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device",
+    "opv_tx_modulate", "opv_tap_tx_checkpoints", "opv_frontend_kernel", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device", "opv_tx_modulate_device_to_host",
 ]
 
 

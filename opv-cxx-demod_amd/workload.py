@@ -26,15 +26,19 @@ def tx_frames(amd, g, n_frames):
     return amd.bert_frames(n_frames, callsign=cs, first=first)
 
 
-def generate(amd, dm, torch, dev, global_ids, n_frames, ebn0):
+def generate(amd, dm, torch, dev, global_ids, n_frames, ebn0, timing=None):
     """Fill HBM with one impaired capture per global stream id. Returns (d_iq [S, 2 n] int16 on `dev`,
     tx [S, n_frames, 134] uint8 numpy, n samples per stream). `dm` is any Demod context on that device (the
-    generator kernels run on its HIP stream)."""
+    generator kernels run on its HIP stream). timing: a dict that receives generate_s, the seconds spent behind the
+    allocation of the (up to 178 GB) capture buffer: BERT frames, device transmit chain, channel tool, for all streams."""
+    import time
     n = amd.lib().opv_tx_modulated_samples(n_frames)
     assert n % 4 == 0
     S = len(global_ids)
     d_clean = torch.empty(2 * n, dtype=torch.int16, device=dev)
     d_iq = torch.empty((S, 2 * n), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     tx = np.empty((S, n_frames, 134), np.uint8)
     for k, g in enumerate(global_ids):
         _, _, f0, sigma, seed = stream_params(g, ebn0)
@@ -42,6 +46,8 @@ def generate(amd, dm, torch, dev, global_ids, n_frames, ebn0):
         dm.modulate_device(tx[k], d_clean.data_ptr())
         dm.channel(d_clean.data_ptr(), d_iq[k].data_ptr(), n, gain=AMP / 16383.0, f0_hz=f0, sigma=sigma, seed=seed)
     dm.sync()
+    if timing is not None:
+        timing["generate_s"] = time.perf_counter() - t0
     return d_iq, tx, n
 
 

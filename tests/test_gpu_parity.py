@@ -604,6 +604,22 @@ def test_device_transmit_chain_lengths_order_and_table_end(amd, golden):
     assert r.stdout.strip().splitlines()[-1] == pins["100"]["sha256"]
 
 
+def test_opv_mod_cli_on_the_gpu(amd, golden):
+    """`bin/opv-mod -G 0`: the reference's modulator CLI with the transmit chain on the device - BERT and raw mode, the same
+    bytes as the reference `opv-mod` (sha256 pins) / as the host chain."""
+    import subprocess
+    _, meta = golden
+    pins = meta["opv_mod_bert_W5NYV"]
+    exe = str(amd.PKG / "bin" / "opv-mod")
+    out = subprocess.run([exe, "-S", "W5NYV", "-B", "100", "-G", "0"], capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()
+    assert hashlib.sha256(out.stdout).hexdigest() == pins["100"]["sha256"]
+    raw = np.random.default_rng(8).integers(0, 256, (5, 134), dtype=np.uint8)
+    a = subprocess.run([exe, "-R", "-G", "0"], input=raw.tobytes(), capture_output=True, timeout=300)
+    b = subprocess.run([exe, "-R"], input=raw.tobytes(), capture_output=True, timeout=300)
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and len(a.stdout) == (5 * 2168 + 100) * 40 * 4
+
+
 def test_batch_mode_100_frames_noisy(amd, oracle, iq100):
     """Batch mode = ONE demodulate() over the whole capture (reference :1173): pos runs to 8.7e6
     (fp64 resolution of the sample position matters there) and there are no chunk artefacts."""
