@@ -1005,12 +1005,20 @@ extern "C" int opv_comm_init_all(void** comms, int n_devices, const int* devices
     if (!rccl().ok) return fail(OPV_ENODEV, "librccl.so.1 could not be loaded (multi-GPU gather needs RCCL)");
     RcclId id;
     if (int rc = rccl().GetUniqueId(&id)) return rccl_fail("ncclGetUniqueId", rc);
+    for (int i = 0; i < n_devices; ++i) comms[i] = nullptr;
     if (int rc = rccl().GroupStart()) return rccl_fail("ncclGroupStart", rc);     // one thread, several devices: inits must be grouped
-    for (int i = 0; i < n_devices; ++i) {
-        HIPCHK(hipSetDevice(devices[i]));
-        if (int rc = rccl().CommInitRank(&comms[i], n_devices, id, i)) { (void)rccl().GroupEnd(); return rccl_fail("ncclCommInitRank", rc); }
+    int rc = 0;
+    bool hip_ok = true;
+    for (int i = 0; i < n_devices && !rc && hip_ok; ++i) {
+        hip_ok = hipSetDevice(devices[i]) == hipSuccess;
+        if (hip_ok) rc = rccl().CommInitRank(&comms[i], n_devices, id, i);
     }
-    if (int rc = rccl().GroupEnd()) return rccl_fail("ncclGroupEnd", rc);
+    const int rc2 = rccl().GroupEnd();
+    if (!hip_ok || rc || rc2) {                          // nothing half-made is handed back
+        for (int i = 0; i < n_devices; ++i) { if (comms[i]) (void)rccl().CommDestroy(comms[i]); comms[i] = nullptr; }
+        if (!hip_ok) return fail(OPV_ENODEV, "opv_comm_init_all: hipSetDevice failed (device ordinal out of range?)");
+        return rccl_fail(rc ? "ncclCommInitRank" : "ncclGroupEnd", rc ? rc : rc2);
+    }
     return OPV_OK;
 }
 
