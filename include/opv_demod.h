@@ -20,7 +20,9 @@
 extern "C" {
 #endif
 
-#define OPV_ABI_VERSION 3
+#define OPV_ABI_VERSION 3   /* 3: + opv_frontend_kernel, opv_tx_bert_frames, opv_tx_modulate_device_to_host, opv_tap_tx_checkpoints,
+                               opv_comm_* / opv_gather_frames(_all); opv_tx_modulate_device runs the whole chain on the device;
+                               an opv_process with nothing new still resumes streams held back by back-pressure */
 
 #define OPV_SAMPLES_PER_SYMBOL 40    /* src/opv-demod.cpp:39  */
 #define OPV_FRAME_BYTES 134          /* :49  */
