@@ -75,3 +75,32 @@ OPV_HD inline double opv_atan2_q(double y, double x) {
     if (x < 0) p = 3.14159265358979323846 - p;
     return y < 0 ? -p : p;
 }
+
+// ---- the same angle from a finer grid and a cubic (k_frontend.hip's row-broadcast body from round 3 on) -----------------------
+// 1025 rows (k/512, |h| <= 1/1024) of f(0) + h g(h), g of degree 2: three FMAs and two 16-byte LDS reads instead of five and
+// three. Approximation error <= 3e-14 rad (tests/test_atan2_host.py asserts 1e-13 against glibc) - deliberately not the 4e-16 of
+// the tables above: the AFC loop turns an angle error e into a steady-state frequency error of ~8600 e Hz (3e-10 Hz), and a soft
+// symbol moves by ~2e-8 of its size per Hz, i.e. by 1e-17: nothing the 1e-5 contract, the 1e-9 the tests assert or a quantiser
+// boundary can see. An argument on the positive x axis still gives exactly 0.
+#ifdef __HIP_DEVICE_COMPILE__
+__constant__
+#else
+static const
+#endif
+double kOpvAtanTabQ3[1025][4] = {
+#include "opv_atan_table_q3.inc"
+};
+
+OPV_HD inline double opv_atan2_q3(double y, double x) {
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const double q = (ay - ax) / (ay + ax);              // in [-1, 1]
+    const double kd = __builtin_rint(q * 512.0);         // nearest expansion point k/512
+    const double h = __builtin_fma(kd, -1.0 / 512.0, q); // |h| <= 1/1024, exact
+    const double* t = kOpvAtanTabQ3[(int)kd + 512];
+    double p = t[3];
+    p = __builtin_fma(p, h, t[2]);
+    p = __builtin_fma(p, h, t[1]);
+    p = __builtin_fma(p, h, t[0]);
+    if (x < 0) p = 3.14159265358979323846 - p;
+    return y < 0 ? -p : p;
+}
