@@ -138,7 +138,11 @@ __device__ inline double clampd(double v, double lo, double hi) { return fmin(fm
 
 // X = exp(j x), x = kfs * fo, |x| <= 0.284 (fo within the AFC clamp of +/-2000 Hz, |kf| <= 49):
 //   sin x = x + x u q(u),  cos x = 1 + u r(u),  u = x^2,
-// q, r near-minimax of degree 4 on u <= 0.0823 (mpmath chebyfit; abs error 1e-19 / 1.3e-18).
+// q a near-minimax cubic, r of degree 4 on u <= 0.0823 (mpmath chebyfit; in fp64 arithmetic sin to 2.2e-16 = one ulp over
+// the whole range, cos to 1.3e-18 before rounding). Round 2 carried a degree-4 q as well (1e-19): one FMA per symbol for
+// digits below the rounding of the products that follow. A cubic r (8e-15 at |x| = 0.287, lane 63's sample with fo at its
+// clamp) was measured too - 9 cycles per symbol faster still - and is NOT used: on the 6 dB / -2 kHz fixture it moved the
+// integer printed by one `raw=%.0f` tracker line (tests/test_gpu_parity.py::test_noisy_configs_vs_reference_fixtures).
 // One asm block: the constants stay in registers as written and hipcc's hazard recogniser does
 // not pad between the dependent FMAs.
 // instantiations of the per-symbol body (see `symbol` in the kernel)
@@ -151,16 +155,15 @@ struct PrevSums {
     double x40c, x40s;  // X[40] = exp(j 40 d) of that symbol
 };
 struct SinCosK {
-    double s0, s1, s2, s3, s4;  // q(u) low -> high
-    double c0, c1, c2, c3, c4;  // r(u) low -> high
+    double s0, s1, s2, s3;      // q(u) low -> high (cubic)
+    double c0, c1, c2, c3, c4;  // r(u) low -> high (degree 4)
 };
 __device__ inline void expj_small(double kfs, double fo, const SinCosK& k, double& xs, double& xc) {
     double x, u, p, r, t;
     asm("v_mul_f64 %[x], %[kfs], %[fo]\n\t"
         "v_mul_f64 %[u], %[x], %[x]\n\t"
-        "v_fma_f64 %[p], %[s4], %[u], %[s3]\n\t"
         "v_fma_f64 %[r], %[c4], %[u], %[c3]\n\t"
-        "v_fma_f64 %[p], %[p], %[u], %[s2]\n\t"
+        "v_fma_f64 %[p], %[s3], %[u], %[s2]\n\t"
         "v_fma_f64 %[r], %[r], %[u], %[c2]\n\t"
         "v_fma_f64 %[p], %[p], %[u], %[s1]\n\t"
         "v_fma_f64 %[r], %[r], %[u], %[c1]\n\t"
@@ -170,7 +173,7 @@ __device__ inline void expj_small(double kfs, double fo, const SinCosK& k, doubl
         "v_fma_f64 %[xc], %[r], %[u], 1.0\n\t"
         "v_fma_f64 %[xs], %[t], %[p], %[x]"
         : [x] "=&v"(x), [u] "=&v"(u), [p] "=&v"(p), [r] "=&v"(r), [t] "=&v"(t), [xs] "=&v"(xs), [xc] "=&v"(xc)
-        : [kfs] "v"(kfs), [fo] "v"(fo), [s0] "v"(k.s0), [s1] "v"(k.s1), [s2] "v"(k.s2), [s3] "v"(k.s3), [s4] "v"(k.s4),
+        : [kfs] "v"(kfs), [fo] "v"(fo), [s0] "v"(k.s0), [s1] "v"(k.s1), [s2] "v"(k.s2), [s3] "v"(k.s3),
           [c0] "v"(k.c0), [c1] "v"(k.c1), [c2] "v"(k.c2), [c3] "v"(k.c3), [c4] "v"(k.c4));
 }
 
@@ -341,8 +344,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         }
     }
     SinCosK sck;
-    sck.s0 = -0x1.5555555555555p-3; sck.s1 = 0x1.1111111110f73p-7; sck.s2 = -0x1.a01a019da51d6p-13;
-    sck.s3 = 0x1.71de256e9bdffp-19; sck.s4 = -0x1.add325df5e3b5p-26;
+    sck.s0 = -0x1.5555555555412p-3; sck.s1 = 0x1.1111110f26395p-7; sck.s2 = -0x1.a019e48059d90p-13; sck.s3 = 0x1.7150a543fadc5p-19;
     sck.c0 = -0x1.0000000000000p-1; sck.c1 = 0x1.5555555555014p-5; sck.c2 = -0x1.6c16c16818f3fp-10;
     sck.c3 = 0x1.a019dfaa26924p-16; sck.c4 = -0x1.276f06eab6283p-22;
     // Loop constants parked in VGPRs: one wave per SIMD has registers to spare, while hipcc
