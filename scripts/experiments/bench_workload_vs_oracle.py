@@ -1,0 +1,65 @@
+"""one-off soak: EVERY stream of bench.py's workload (64 streams x 1000 frames, 16 dB, f0 -1500..+1500 Hz: BASELINE configs[3])
+through the HIP path in one context, and through the CPU oracle (8 worker processes, one stream at a time in host memory):
+frames, Viterbi metrics, sync positions, tracker events (kind / count / symbol), symbol count, offset estimate of every stream.
+tests/test_gpu_parity.py::test_config3_full_size_sampled_streams does four of the 64 in every suite run."""
+import sys
+import time
+from concurrent.futures import ProcessPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def oracle_job(x):
+    from oracle_lib import Oracle
+    e = Oracle().receive(x, streaming=True, want_soft=False)
+    return {k: e[k] for k in ("frames", "metrics", "frame_sym", "events", "n_soft", "est_offset", "final_freq_offset")}
+
+
+def main():
+    import torch
+    from __graft_entry__ import load_opv_amd, load_pkg_module
+    amd, workload = load_opv_amd(), load_pkg_module("workload")
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    F = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    dev = torch.device("cuda", 0)
+    n = amd.lib().opv_tx_modulated_samples(F)
+    dm = amd.Demod(S, max_samples=n + 64, streaming=True)
+    d_iq, tx, n = workload.generate(amd, dm, torch, dev, range(S), F, 16.0)
+    for k in range(S):
+        dm.attach(k, d_iq[k].data_ptr(), n, eof=True)
+    t0 = time.time()
+    dm.process()
+    dm.sync()
+    print(f"HIP path: {S} streams x {F} frames in {time.time() - t0:.2f} s ({dm.frontend_kernel()})", flush=True)
+    bad = 0
+    with ProcessPoolExecutor(8) as pool:
+        pending = {}
+        for k in range(S):
+            pending[k] = pool.submit(oracle_job, d_iq[k].cpu().numpy())
+            if len(pending) >= 8 or k == S - 1:
+                for j, fut in sorted(pending.items()):
+                    e = fut.result()
+                    fr, meta = dm.pop_frames(j)
+                    ev = dm.pop_events(j)
+                    st = dm.state(j)
+                    ok = (np.array_equal(fr, e["frames"]) and np.array_equal(meta["viterbi_metric"], e["metrics"])
+                          and np.array_equal(meta["release_symbol"], e["frame_sym"]) and len(ev) == len(e["events"])
+                          and all(np.array_equal(ev[f], e["events"][f]) for f in ("kind", "count", "sym_idx"))
+                          and st.total_symbols == e["n_soft"] and st.est_offset_hz == e["est_offset"]
+                          and abs(st.freq_offset_hz - e["final_freq_offset"]) < 1e-6 and st.edge_ties == 0)
+                    bad += not ok
+                    print(f"stream {j:3d}: {len(fr)} frames, {int((fr == tx[j][:len(fr)]).all(axis=1).sum())} equal to the transmitted ones, "
+                          f"{len(ev)} tracker events, est {st.est_offset_hz:+.0f} Hz, final AFC {st.freq_offset_hz:+.3f} Hz (oracle {e['final_freq_offset']:+.3f}), "
+                          f"offset_ties {st.offset_ties}: {'== oracle' if ok else 'DIFFERS'}", flush=True)
+                pending = {}
+    print(f"{S - bad} of {S} streams equal the oracle in every frame, metric, sync position and tracker event")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
