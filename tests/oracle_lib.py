@@ -546,3 +546,61 @@ def run_under_reference_modem(child, iq, piece=16384, recv_timeout=60.0, verbose
     th.join(5)
     rx.close()
     return grams, p.returncode, (err[0].decode("utf-8", "replace") if err else "")
+
+
+def run_reference_modem_loopback(child, frames, gap_s=0.12, settle_s=4.0, start_s=0.4):
+    """The boundary's OTHER real caller: the reference's `opv-modem -l -d <child>` (loopback / repeater mode,
+    src/opv-modem.cpp:855-1000). The parent takes 134-byte frames by UDP, modulates each with its own persistent modulator,
+    writes the frame's 86 720 samples to a PERSISTENT `<child> -s -r` (PersistentDemodulator, :348-468: fork, execlp, child's
+    stderr to /dev/null, blocking 347 KB writes, non-blocking reads of the decoded records) and sends every decoded frame back
+    to the sender. `frames` ([K, 134] uint8) are sent one datagram at a time, `gap_s` apart - a live link, not a file; returns
+    (list of returned datagrams in arrival order, the parent's stderr text). The demodulator's one-frame latency shows here:
+    frame k comes back once frame k + 1 has been sent."""
+    import signal
+    import socket
+    import subprocess
+    import time
+    modem = ref_binary("opv-modem")
+    assert modem is not None, "oracle/_ref/opv-modem is missing (make -C oracle ref, in the build container)"
+    probe = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    probe.bind(("127.0.0.1", 0))
+    port = probe.getsockname()[1]
+    probe.close()
+    p = subprocess.Popen([str(modem), "-l", "-p", str(port), "-d", str(child)], stdin=subprocess.DEVNULL,
+                         stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    so = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+    so.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1 << 22)
+    so.bind(("127.0.0.1", 0))
+    so.setblocking(False)
+    got = []
+
+    def drain():
+        while True:
+            try:
+                got.append(so.recv(4096))
+            except BlockingIOError:
+                return
+    try:
+        time.sleep(start_s)                                  # the parent binds its port and starts the child
+        assert p.poll() is None, p.stderr.read().decode("utf-8", "replace")
+        for f in np.ascontiguousarray(frames, np.uint8).reshape(-1, FRAME_BYTES):
+            so.sendto(f.tobytes(), ("127.0.0.1", port))
+            t_end = time.time() + gap_s
+            while time.time() < t_end:
+                drain()
+                time.sleep(0.005)
+        t_end, n_last = time.time() + settle_s, -1
+        while time.time() < t_end:                           # until nothing new has arrived for a while
+            drain()
+            if len(got) != n_last:
+                n_last, t_end = len(got), time.time() + settle_s
+            time.sleep(0.02)
+    finally:
+        p.send_signal(signal.SIGINT)                         # the parent's own shutdown path (it ends its child itself)
+        try:
+            err = p.communicate(timeout=30)[1]
+        except subprocess.TimeoutExpired:
+            p.kill()
+            err = p.communicate()[1]
+        so.close()
+    return got, err.decode("utf-8", "replace")

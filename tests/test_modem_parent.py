@@ -14,7 +14,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from oracle_lib import Oracle, impair, ref_binary, run_under_reference_modem
+from oracle_lib import Oracle, impair, ref_binary, run_reference_modem_loopback, run_under_reference_modem
 
 ROOT = Path(__file__).resolve().parent.parent
 GOLD = ROOT / "tests" / "golden"
@@ -64,3 +64,32 @@ def test_reference_modem_drives_our_opv_demod(cases, name, piece):
     assert OURS.exists()
     iq, expected, m = cases[name]
     _check(OURS, iq, expected, piece)
+
+
+# ---- the reference's loopback / repeater mode: a PERSISTENT child fed one frame at a time over a live link ---------------
+def _loopback(child, oracle):
+    sent = oracle.bert_frames(9, "KB5MU", 0x123456, 40)
+    grams, err = run_reference_modem_loopback(child, sent)
+    assert all(len(g) == 134 for g in grams), sorted({len(g) for g in grams})
+    got = np.frombuffer(b"".join(grams), np.uint8).reshape(-1, 134)
+    # frame k returns once frame k + 1 has been modulated into the child (the demodulator's one-frame latency,
+    # src/opv-demod.cpp:221): 8 of 9 come back, in order, untouched
+    assert len(got) == len(sent) - 1 and np.array_equal(got, sent[:-1]), (len(got), err[-1500:])
+    assert "TX:  9 frames" in err and "RX:  8 frames" in err, err[-800:]
+
+
+@pytest.mark.skipif(ref_binary("opv-modem") is None or ref_binary("opv-demod") is None, reason="oracle/_ref not built")
+def test_reference_loopback_pair(oracle):
+    """`opv-modem -l -d oracle/_ref/opv-demod`: what the reference pair itself does on a live link (the behaviour the GPU
+    test below demands of our child)."""
+    _loopback(ref_binary("opv-demod"), oracle)
+
+
+@pytest.mark.gpu
+def test_reference_modem_loopback_with_our_opv_demod(oracle):
+    """`oracle/_ref/opv-modem -l -d opv-cxx-demod_amd/bin/opv-demod`: the reference's loopback server (src/opv-modem.cpp:855-1000)
+    keeps ONE child alive (PersistentDemodulator :348-468: child's stderr to /dev/null, a blocking 347 KB write per frame,
+    non-blocking reads), modulates every UDP frame it receives into it and returns what the child decodes. Nine frames sent 120
+    ms apart: eight come back, in order, byte for byte - the reference pair's behaviour (test above)."""
+    assert ref_binary("opv-modem") is not None, "oracle/_ref/opv-modem did not travel with the snapshot"
+    _loopback(OURS, oracle)
