@@ -88,6 +88,7 @@ def cpu_baseline(iq_bytes, n_samples):
                            stderr=subprocess.DEVNULL)
         dt = time.perf_counter() - t0
         nf = len(p.stdout) // 134
+        cpu_baseline.ref_stdout = p.stdout              # (kept for extras.cli_drop_in: our CLI on the same bytes)
         return {"value": n_samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "reference",
                 "sample": f"oracle/_ref/opv-demod -s -r -q on the clean {n_samples // FRAME_SAMPLES}-frame "
                           f"capture via a pipe ({dt:.2f} s, {nf} frames out)"}
@@ -101,6 +102,22 @@ def cpu_baseline(iq_bytes, n_samples):
     return {"value": n_samples / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
             "sample": f"oracle/opv_oracle.c oro_receive on the clean {n_samples // FRAME_SAMPLES}-frame capture "
                       f"in memory ({dt:.2f} s, {len(r['frames'])} frames out)"}
+
+
+def cli_drop_in(iq_bytes, n_samples):
+    """The drop-in measured the way the reference CPU binary is (cpu_baseline): opv-cxx-demod_amd/bin/opv-demod -s -r -q as
+    a child process, the same capture through a pipe - process start, HIP initialisation, stdin reads, a round of kernels per
+    chunk and the 134-byte writes included; its stdout against the reference child's."""
+    exe = ROOT / "opv-cxx-demod_amd" / "bin" / "opv-demod"
+    if not exe.exists():
+        return None
+    t0 = time.perf_counter()
+    p = subprocess.run([str(exe), "-s", "-r", "-q"], input=iq_bytes, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    dt = time.perf_counter() - t0
+    ref = getattr(cpu_baseline, "ref_stdout", None)
+    return {"Msamples/s": round(n_samples / dt / 1e6, 2), "s": round(dt, 2), "exit": p.returncode, "frames_out": len(p.stdout) // 134,
+            "stdout_identical_to_reference": (p.stdout == ref) if ref is not None else None,
+            "what": "bin/opv-demod -s -r -q (one stream = one wavefront) on the capture the reference binary was timed on, via a pipe"}
 
 
 def cpu_all_cores(iq_bytes, n_samples):
@@ -526,6 +543,7 @@ def main():
         base = d_base.cpu().numpy()
         raw = base.tobytes()
         out["cpu_baseline"] = cpu_baseline(raw, n)
+        out["extras"]["cli_drop_in"] = cli_drop_in(raw, n)
         out["extras"]["cpu_baseline_all_cores"] = cpu_all_cores(raw, n)
         out["setup"] = {"device_modulate_s_all_streams": round(t_mod, 2),
                         "device_modulate_one_stream": {"s": round(t_dev_mod, 3), "Msamples/s": round(n / t_dev_mod / 1e6, 1),
