@@ -3,6 +3,7 @@
 // (-r), human text on stderr, flags -q -r -s -c -a -o -p -h (-c/-p: the batch Costas-loop demodulator,
 // csrc/k_coherent.hip - prefix parity only), exit status 0 iff at least one frame decoded. All arithmetic runs on the MI355X through
 // the C ABI in include/opv_demod.h; this file only moves bytes and prints.
+#include <poll.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -311,19 +312,27 @@ int main(int argc, char** argv) {
         Sink sink{ctx, o};
         std::vector<int16_t> blk;
         uint64_t pushed = 0, since = 0;
+        // A round's results are delivered at once when the source is live (nothing waiting on stdin: latency counts), and
+        // one read later when it is not (a file, a fast pipe): the next block is then read and copied to the device while the
+        // kernels of this round run, instead of the host waiting for them first.
+        bool pending = false;
+        auto stdin_has_data = [] { pollfd p{STDIN_FILENO, POLLIN, 0}; return poll(&p, 1, 0) > 0 && (p.revents & (POLLIN | POLLHUP)); };
         for (;;) {
             blk.clear();
             long ns = read_block(blk);
             if (ns <= 0) break;
             if (opv_push_iq(ctx, 0, blk.data(), (size_t)ns) < 0) return die("opv_push_iq");
+            if (pending) { if (sink.drain() < 0) return die("drain"); pending = false; }
             pushed += (uint64_t)ns;
             since += (uint64_t)ns;
             if (since >= OPV_CHUNK_SAMPLES - 64) {  // a chunk boundary may have been crossed
                 if (opv_process(ctx) < 0) return die("opv_process");
-                if (sink.drain() < 0) return die("drain");
+                if (stdin_has_data()) pending = true;
+                else if (sink.drain() < 0) return die("drain");
                 since = 0;
             }
         }
+        if (pending && sink.drain() < 0) return die("drain");
         if (opv_flush(ctx, 0) < 0 || opv_process(ctx) < 0) return die("opv_flush");
         if (sink.drain() < 0) return die("drain");
         if (finish(ctx, sink) < 0) return die("finish");
