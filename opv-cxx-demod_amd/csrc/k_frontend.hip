@@ -88,8 +88,8 @@ constexpr uint32_t kAhead = 56;                 // highest tap is floor(pos) + 5
 static_assert((kRing & (kRing - 1)) == 0, "ring must be a power of two");
 
 // LDS map (bytes): WPB x (ring | guard), then ONE atan table shared by the workgroup's waves:
-//   row-broadcast body (k_msk_frontend_rb / _rb_wg4): 1025 rows x 4 doubles (opv_atan_table_q3.inc: pi/4 + atan(q) at q = k/512,
-//     a cubic, 3e-14 rad: opv_atan2.h says why that is plenty) = 32 800 B -> 49 200 B for one wave, 98 400 B for four;
+//   row-broadcast body (k_msk_frontend_rb / _rb_wg4): 1025 rows x 4 doubles (opv_atan_table_q3r.inc: pi/4 + atan(q) around q = k/512,
+//     a cubic in q itself, 4e-14 rad: opv_atan2.h says why that is plenty) = 32 800 B -> 49 200 B for one wave, 98 400 B for four;
 //   round-1 body (k_msk_frontend / _wg4 / _dual): 33 rows x kTabRow doubles (c0..c8, pad) = 2 640 B -> 19 040 B / 68 240 B
 constexpr uint32_t kTabOff = kRingBytes + kGuardBytes;   // 16400
 constexpr uint32_t kTabRow = 10;
@@ -353,7 +353,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     double kc_tiny = 1e-100;
     asm volatile("" : "+v"(kc_tiny));
     double kc_halfpi = 1.57079632679489661923, kc_32 = 32.0, kc_m1_32 = -1.0 / 32.0, kc_gain = st.afc_alpha * (kSymRate / kTwoPi);
-    // rows per unit of the angle table, its inverse, 1.5 * 2^52 + the row offset (row-broadcast body: the 1025 rows of opv_atan2_q3)
+    // rows per unit of the angle table, its inverse, 1.5 * 2^52 + the row offset (row-broadcast body: the 1025 rows of opv_atan2_q3r)
     [[maybe_unused]] double kc_64 = 512.0, kc_m1_64 = -1.0 / 512.0, kc_magic = 6755399441055744.0 + 512.0;
     asm volatile("" : "+v"(kc_64), "+v"(kc_m1_64), "+v"(kc_magic));
     asm volatile("" : "+v"(kc_tfmax), "+v"(kc_beta), "+v"(kc_alpha), "+v"(kc_fomax), "+v"(kc_eps));
@@ -822,7 +822,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         // every lane (one instruction per double instead of two v_readlane + the SGPR-operand restrictions), and the four
         // early / late energies are formed lane-parallel (square, row_ror:8, add: Re at t, Im at t + 8), the dominant
         // tone's pair selected lane-parallel (row_shl:2), before two of them are handed out. The phase detector's angle
-        // comes without the octant fix-up (opv_atan2.h: opv_atan2_q3, 1025-row table of pi/4 + atan, a cubic; round 2: 257 rows, degree 5).
+        // comes without the octant fix-up (opv_atan2.h: opv_atan2_q3r, 1025-row table of pi/4 + atan, cubics in the argument itself; round 2: 257 rows, degree 5).
         // Scheduling notes: hipcc counts an asm block as no wait state and pads the fp64 instruction behind one with an
         // s_nop; every block here is therefore followed by a 32-bit instruction that was needed anyway, and the wait
         // states DPP reads / permlane swaps need behind a VALU write are filled with useful instructions, not s_nop.
@@ -972,8 +972,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 // nearest expansion point k/128, k = -128..128, by the 1.5 * 2^52 trick: the sum's low word IS the row index
                 // k + 128, and subtracting the constant gives k as a double - no v_rndne, no v_cvt
                 const double kt = fma(ratio, kc_64, kc_magic);
-                const double kd = kt - kc_magic;
-                h = fma(kd, kc_m1_64, ratio);                       // |h| <= 1/1024
+                h = ratio;                                          // (the rows' cubics are written in the argument itself)
                 const unsigned char* rowb = reinterpret_cast<const unsigned char*>(atab) + ((unsigned)dlo(kt) << 5);
                 const double2* trow = reinterpret_cast<const double2*>(rowb);
                 c23 = trow[1]; c01 = trow[0];
@@ -994,7 +993,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0xC17F);                 // lgkmcnt(1): the table row landed (only the tap read may be in flight)
                 __builtin_amdgcn_sched_barrier(0);
-                pd = fma(c23.y, h, c23.x);                          // cubic on the 1025-row table: pi/4 + atan(q) to 3e-14 rad
+                pd = fma(c23.y, h, c23.x);                          // the row's cubic in q: pi/4 + atan(q) to 4e-14 rad
                 pd = fma(pd, h, c01.y);
                 pd = fma(pd, h, c01.x);
                 pd = fma(sx, pd, pd_off);
@@ -1124,7 +1123,7 @@ constexpr uint32_t kAtanQBytes = 1025 * 32;
 template <int NT>
 __device__ __forceinline__ void load_atan_table_q(unsigned char* lds_tab) {
     double* atab = reinterpret_cast<double*>(lds_tab);
-    for (int i = threadIdx.x; i < 1025 * 4; i += NT) atab[i] = (&kOpvAtanTabQ3[0][0])[i];
+    for (int i = threadIdx.x; i < 1025 * 4; i += NT) atab[i] = (&kOpvAtanTabQ3R[0][0])[i];
 }
 extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_rb(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
                                                                     int n_streams) {

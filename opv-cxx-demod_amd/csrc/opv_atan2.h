@@ -104,3 +104,27 @@ OPV_HD inline double opv_atan2_q3(double y, double x) {
     if (x < 0) p = 3.14159265358979323846 - p;
     return y < 0 ? -p : p;
 }
+
+// ---- and with the cubics written in the argument itself (what k_frontend.hip's row-broadcast body evaluates) --------------
+// Row k of kOpvAtanTabQ3R is row k of kOpvAtanTabQ3 re-expanded around 0: the same function values up to Horner's roundings
+// (~3e-16), without forming k as a double and h = q - k/512: two instructions per symbol. The axis is no longer exact
+// (opv_atan2_q3r(0, x > 0) ~ 1e-16): 1e-15 Hz per symbol on a frequency state compared to 1e-7.
+#ifdef __HIP_DEVICE_COMPILE__
+__constant__
+#else
+static const
+#endif
+double kOpvAtanTabQ3R[1025][4] = {
+#include "opv_atan_table_q3r.inc"
+};
+
+OPV_HD inline double opv_atan2_q3r(double y, double x) {
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const double q = (ay - ax) / (ay + ax);              // in [-1, 1]
+    const double* t = kOpvAtanTabQ3R[(int)__builtin_rint(q * 512.0) + 512];
+    double p = __builtin_fma(t[3], q, t[2]);
+    p = __builtin_fma(p, q, t[1]);
+    p = __builtin_fma(p, q, t[0]);
+    if (x < 0) p = 3.14159265358979323846 - p;
+    return y < 0 ? -p : p;
+}

@@ -110,3 +110,19 @@ def test_atan2_q3_table_is_within_its_stated_error(tmp_path):
     chk.write_text('#include <stdio.h>\n#include "opv_atan2.h"\nint main(){printf("%a %a\\n", opv_atan2_q3(0.0, 1.0), opv_atan2_q3(0.0, 5e7));return 0;}')
     subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", str(ROOT / "opv-cxx-demod_amd" / "csrc"), str(chk), "-o", str(tmp_path / "a"), "-lm"], check=True)
     assert subprocess.run([str(tmp_path / "a")], capture_output=True, text=True, check=True).stdout.split() == ["0x0p+0", "0x0p+0"]
+
+
+def test_atan2_q3r_is_q3_written_in_the_argument(tmp_path):
+    """opv_atan2_q3r (what the kernel evaluates: the same 1025 cubics re-expanded in the argument itself, no k / h): within
+    1e-13 rad of glibc and within 1e-15 of opv_atan2_q3 over 4e6 random arguments."""
+    src = SRC.replace("double a = opv_atan2(y, x), b = atan2(y, x), e = fabs(a - b);",
+                      "double a = opv_atan2_q3r(y, x), b = atan2(y, x), e = fabs(a - b); if (fabs(a - opv_atan2_q3(y, x)) > 1e-15) e = 1.0;")
+    src = src.replace("opv_atan2(ax[k][0], ax[k][1])", "opv_atan2_q3r(ax[k][0], ax[k][1])")
+    assert "opv_atan2_q3r(y, x)" in src
+    c = tmp_path / "t.cpp"
+    c.write_text(src)
+    exe = tmp_path / "t"
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", str(ROOT / "opv-cxx-demod_amd" / "csrc"), str(c), "-o",
+                    str(exe), "-lm"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert float(out[0]) < 1e-13
