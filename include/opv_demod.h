@@ -229,6 +229,10 @@ int opv_tap_offset_energies(opv_ctx* ctx, int stream, double* out134);
  * chip held (cycles / ticks x 100 MHz); no counterpart in the reference. */
 int opv_tap_wave_info(opv_ctx* ctx, int stream, uint64_t out[4]);
 
+/* Workgroups of each hot-path kernel the runtime can keep resident per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor), in the
+ * order k_msk_frontend_rb, _rb_wg4, k_msk_frontend_x4, _x4_wg4, k_frame_decode, k_frame_scale. Diagnostic. */
+int opv_tap_occupancy(opv_ctx* ctx, int out[6]);
+
 /* Stand-alone FrameDecoder::decode (src/opv-demod.cpp:854-898) on n_frames payloads of
  * 2144 host doubles each. Optional taps: q (quantised, :862-866), deint (:869-871),
  * bits (Viterbi hard decisions, :874-875). metrics[i] = path metric or -1. */

@@ -764,6 +764,16 @@ extern "C" int opv_tap_wave_info(opv_ctx* c, int s, uint64_t out[4]) {
     return OPV_OK;
 }
 
+extern "C" int opv_tap_occupancy(opv_ctx* c, int out[6]) {
+    if (!c || !out) return fail(OPV_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    const struct { const void* k; int threads; } ks[6] = {
+        {(const void*)k_msk_frontend_rb, 64}, {(const void*)k_msk_frontend_rb_wg4, 256}, {(const void*)k_msk_frontend_x4, 64},
+        {(const void*)k_msk_frontend_x4_wg4, 256}, {(const void*)k_frame_decode, 64}, {(const void*)k_frame_scale, 64}};
+    for (int i = 0; i < 6; ++i) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[i], ks[i].k, ks[i].threads, 0));
+    return OPV_OK;
+}
+
 extern "C" int opv_decode_payloads(opv_ctx* c, const double* soft, size_t n, uint8_t* out, int32_t* metrics,
                                    int8_t* q, int8_t* deint, uint8_t* bits) {
     if (!c || !soft || !out || !metrics) return fail(OPV_EINVAL, "null argument");

@@ -32,7 +32,7 @@ EXPORTS = [
     "opv_attach_device_iq", "opv_process", "opv_sync", "opv_set_frontend", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_comm_unique_id", "opv_comm_init", "opv_comm_init_all",
     "opv_comm_destroy", "opv_gather_frames", "opv_gather_frames_all", "opv_tap_soft", "opv_tap_chunks",
-    "opv_tap_offset_energies", "opv_tap_wave_info", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_bert_frames", "opv_tx_modulated_samples",
+    "opv_tap_offset_energies", "opv_tap_wave_info", "opv_tap_occupancy", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_bert_frames", "opv_tx_modulated_samples",
     "opv_tx_modulate", "opv_tap_tx_checkpoints", "opv_frontend_kernel", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device", "opv_tx_modulate_device_to_host",
 ]
 
@@ -127,6 +127,7 @@ def lib():
         L.opv_tap_chunks.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
         L.opv_tap_offset_energies.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.opv_tap_wave_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.opv_tap_occupancy.argtypes = [C.c_void_p, C.c_void_p]
         L.opv_decode_payloads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
         L.opv_tx_bert_frame.restype = None
@@ -305,6 +306,13 @@ class Demod:
         out = (C.c_uint64 * 4)()
         _chk(lib().opv_tap_wave_info(self.h, stream, out))
         return tuple(int(v) for v in out)
+
+    def occupancy(self):
+        """workgroups per CU the runtime can keep resident, per hot-path kernel (opv_tap_occupancy)"""
+        out = (C.c_int * 6)()
+        _chk(lib().opv_tap_occupancy(self.h, out))
+        return dict(zip(("k_msk_frontend_rb", "k_msk_frontend_rb_wg4", "k_msk_frontend_x4", "k_msk_frontend_x4_wg4", "k_frame_decode",
+                         "k_frame_scale"), [int(v) for v in out]))
 
     def decode_payloads(self, soft, taps=False):
         soft = np.ascontiguousarray(soft, np.float64).reshape(-1, ENCODED_BITS)
