@@ -830,10 +830,9 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         [[maybe_unused]] auto symbol_r = [&](auto tag, PrevSums& cur, const PrevSums& prv) {
             constexpr bool kFirst = decltype(tag)::first;
             constexpr bool kWide = decltype(tag)::wide;
-            const int s0r = (int)(short)(w0 & 0xFFFF), s0i = w0 >> 16;      // ref :1023
-            const int d_r = (int)(short)(w1 & 0xFFFF) - s0r, d_i = (w1 >> 16) - s0i;
-            const double lr = fma(f, (double)d_r, (double)s0r);              // ref :122-128
-            const double li = fma(f, (double)d_i, (double)s0i);
+            // The LO factor FIRST: it needs fo only, and its twelve instructions are the cover the tap read of the previous
+            // symbol's tail still lacked (round 3: without that read the kernel ran 34 cycles per symbol faster, i.e. ~26 of
+            // its latency were exposed when the unpack below came first)
             double xs, xc;
             if constexpr (kWide) {
                 if (__builtin_expect(uni_lt(2000.0, fabs(fo)), 0)) sincos(kfs * fo, &xs, &xc);
@@ -846,6 +845,10 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             uint32_t soft_off_next = soft_off + 8u;                 // (32-bit filler behind the asm block above)
             asm volatile("" : "+v"(soft_off_next));
             __builtin_amdgcn_sched_barrier(0);
+            const int s0r = (int)(short)(w0 & 0xFFFF), s0i = w0 >> 16;      // ref :1023
+            const int d_r = (int)(short)(w1 & 0xFFFF) - s0r, d_i = (w1 >> 16) - s0i;
+            const double lr = fma(f, (double)d_r, (double)s0r);              // ref :122-128
+            const double li = fma(f, (double)d_i, (double)s0i);
             const double zr = fma(lr, xc, li * xs);                         // Z = Lam * conj(X)
             const double zi = fma(li, xc, -(lr * xs));
             __builtin_amdgcn_sched_barrier(0);
