@@ -1137,7 +1137,7 @@ def test_reference_makefile_targets_with_our_binaries():
     assert p.returncode == 0 and p.stdout == frames, "raw mode: the three frames did not come back byte for byte"
 
 
-@pytest.mark.parametrize("seed", [20261003 + k for k in range(int(os.environ.get("OPV_FUZZ_SEEDS", "1")))])
+@pytest.mark.parametrize("seed", [int(os.environ.get("OPV_FUZZ_BASE", "20261003")) + k for k in range(int(os.environ.get("OPV_FUZZ_SEEDS", "1")))])
 def test_clock_rate_error_and_random_channels_fuzz(amd, oracle, iq10, iq100, seed):
     """Differential fuzz: 24 streams in one context, each with its own sample-clock error (the timing
     loop then drifts through integer sample boundaries, the chunk grid moves: leftovers from 18 to 50), carrier offset, level, Eb/N0 and a random truncation point; both -s and batch mode."""
@@ -1156,12 +1156,17 @@ def test_clock_rate_error_and_random_channels_fuzz(amd, oracle, iq10, iq100, see
         d = amd.Demod(len(caps), max_samples=nmax + 64, streaming=streaming)
         got = d.receive(caps)
         kinds = set()
+        guarded = 0
         for k, x in enumerate(caps):
             exp = oracle.receive(x, streaming=streaming)
-            check_stream(amd, got[k], exp, f"fuzz {k} streaming={streaming}")
+            # the offset search's near-tie guard may fire on a random channel (seed 777017, stream 11: two candidates): that
+            # path is reproduced - check_stream compares the estimate with the oracle's - so it is counted, not forbidden
+            check_stream(amd, got[k], exp, f"fuzz {k} streaming={streaming}", offset_ties=None)
+            guarded += got[k]["state"].offset_ties != 0
             if streaming:
                 kinds.update(int(v) for v in exp["chunks"][:-1, 3])
         d.close()
+        assert guarded <= 2, f"the near-tie guard fired on {guarded} of {len(caps)} streams"
         if streaming:
             assert len(kinds) >= 8, kinds        # the clock error really moved the chunk grid (leftovers 18..50)
 
