@@ -326,6 +326,9 @@ int main(int argc, char** argv) {
             pushed += (uint64_t)ns;
             since += (uint64_t)ns;
             if (since >= OPV_CHUNK_SAMPLES - 64) {  // a chunk boundary may have been crossed
+                // a backlog on stdin (a file, a fast pipe): up to eight chunks go into one round - the launches and the
+                // hand-shake of a round are paid once; a live source never has a backlog and is served chunk by chunk
+                if (since < 8ull * OPV_CHUNK_SAMPLES && stdin_has_data()) continue;
                 if (opv_process(ctx) < 0) return die("opv_process");
                 if (stdin_has_data()) pending = true;
                 else if (sink.drain() < 0) return die("drain");
