@@ -20,7 +20,8 @@
 extern "C" {
 #endif
 
-#define OPV_ABI_VERSION 3   /* 3: + opv_frontend_kernel, opv_tx_bert_frames, opv_tx_modulate_device_to_host, opv_tap_tx_checkpoints,
+#define OPV_ABI_VERSION 4   /* 4: + opv_tx_stream_* (the host modulator with its state carried from call to call), opv_tap_tx_frame;
+                               3: + opv_frontend_kernel, opv_tx_bert_frames, opv_tx_modulate_device_to_host, opv_tap_tx_checkpoints,
                                opv_comm_* / opv_gather_frames(_all); opv_tx_modulate_device runs the whole chain on the device;
                                an opv_process with nothing new still resumes streams held back by back-pressure */
 
@@ -247,6 +248,22 @@ void opv_tx_bert_frame(const char* callsign, uint32_t token, uint32_t frame_num,
 void opv_tx_bert_frames(const char* callsign, uint32_t token, uint32_t first_frame, size_t n_frames, uint8_t* out134);
 size_t opv_tx_modulated_samples(size_t n_frames);
 size_t opv_tx_modulate(const uint8_t* frames134, size_t n_frames, int16_t* iq_out);
+/* The same modulator as an object that carries its state from call to call (the reference's HDLModulator,
+ * src/opv-mod.cpp:219-291: two free-running NCOs, the differential sign, the symbol parity), for a source that produces frames
+ * as it goes - `opv-mod -R` on a live pipe (:473-498), `opv-mod -c` (:503-524: one reset per pass over the BERT frames).
+ * create = a modulator after reset() (:221-226); opv_tx_stream_frames appends n_frames x 2168 x 40 samples to iq_out and
+ * returns that count; opv_tx_stream_tail writes the 100 silent symbols that end a run (:528-529; 4000 samples, no state).
+ * Any split of a run into calls gives the bytes of one opv_tx_modulate call. Host only, needs no device. */
+/* Parity tap of the bit-level half (src/opv-mod.cpp:158-213): one frame after the randomiser (134 bytes), after the
+ * convolutional encoder (2144 bits, one per byte, encoder order) and after the interleaver (on-air order). Any output may be
+ * NULL. What `opv-mod -v` prints the first bytes / bits of (:171-183,198-209,326-329). */
+void opv_tap_tx_frame(const uint8_t* frame134, uint8_t* randomized134, uint8_t* coded2144, uint8_t* interleaved2144);
+typedef struct opv_tx_stream opv_tx_stream;
+opv_tx_stream* opv_tx_stream_create(void);
+void opv_tx_stream_reset(opv_tx_stream* st);
+size_t opv_tx_stream_frames(opv_tx_stream* st, const uint8_t* frames134, size_t n_frames, int16_t* iq_out);
+size_t opv_tx_stream_tail(int16_t* iq_out);
+void opv_tx_stream_destroy(opv_tx_stream* st);
 /* Device-side transmit chain: same result as opv_tx_modulate, written straight into HBM
  * (d_iq_out: device pointer, 16-byte aligned, opv_tx_modulated_samples(n_frames) samples). The whole chain of
  * src/opv-mod.cpp:97-291 runs on the device: randomiser, convolutional encoder, interleaver and sync word per frame

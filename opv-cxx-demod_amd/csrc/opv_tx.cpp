@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -53,8 +54,8 @@ inline size_t interleave_pos(size_t i) {  // opv-mod.cpp:145-149
     return (p & ~size_t(7)) | (7 - (p & 7));
 }
 
-// 24 sync bits + 2144 interleaved coded bits of one frame, in on-air order
-void frame_symbols(const uint8_t* payload, uint8_t* sym /*2168*/) {
+// 24 sync bits + 2144 interleaved coded bits of one frame, in on-air order; `linear` (optional): the coded bits in encoder order
+void frame_symbols(const uint8_t* payload, uint8_t* sym /*2168*/, uint8_t* linear = nullptr /*2144*/) {
     for (int b = 0; b < 24; ++b) sym[b] = (kSync >> (23 - b)) & 1u;
     uint8_t* coded = sym + 24;
     unsigned sr = 0;
@@ -64,8 +65,10 @@ void frame_symbols(const uint8_t* payload, uint8_t* sym /*2168*/) {
         for (int bit = 7; bit >= 0; --bit) {
             const unsigned in = (v >> bit) & 1u;
             const unsigned reg = (in << 6) | sr;
-            coded[interleave_pos(o++)] = (uint8_t)__builtin_parity(reg & 0x4F);
-            coded[interleave_pos(o++)] = (uint8_t)__builtin_parity(reg & 0x6D);
+            const uint8_t g1 = (uint8_t)__builtin_parity(reg & 0x4F), g2 = (uint8_t)__builtin_parity(reg & 0x6D);
+            if (linear) { linear[o] = g1; linear[o + 1] = g2; }
+            coded[interleave_pos(o++)] = g1;
+            coded[interleave_pos(o++)] = g2;
             sr = ((sr << 1) | in) & 0x3F;
         }
     }
@@ -107,6 +110,17 @@ extern "C" void opv_tx_bert_frame(const char* callsign, uint32_t token, uint32_t
     for (unsigned i = 0; i < OPV_FRAME_BYTES - 12; ++i) out[12 + i] = (uint8_t)(frame_num + i);
 }
 
+extern "C" void opv_tap_tx_frame(const uint8_t* frame134, uint8_t* randomized134, uint8_t* coded2144, uint8_t* interleaved2144) {
+    if (!frame134) return;
+    if (randomized134) for (int i = 0; i < OPV_FRAME_BYTES; ++i) randomized134[i] = frame134[i] ^ kLfsr.b[i];
+    if (coded2144 || interleaved2144) {
+        uint8_t sym[OPV_FRAME_SYMBOLS], lin[OPV_ENCODED_BITS];
+        frame_symbols(frame134, sym, lin);
+        if (coded2144) std::memcpy(coded2144, lin, OPV_ENCODED_BITS);
+        if (interleaved2144) std::memcpy(interleaved2144, sym + 24, OPV_ENCODED_BITS);
+    }
+}
+
 extern "C" void opv_tx_bert_frames(const char* callsign, uint32_t token, uint32_t first_frame, size_t n_frames,
                                    uint8_t* out) {
     for (size_t k = 0; k < n_frames; ++k) opv_tx_bert_frame(callsign, token, first_frame + (uint32_t)k, out + k * OPV_FRAME_BYTES);
@@ -117,9 +131,9 @@ extern "C" size_t opv_tx_modulated_samples(size_t n_frames) {
 }
 
 // ---- pieces shared with the device modulator (opv_tx_internal.h) ----------------------------
-void opv_tx_symbol_codes(const uint8_t* frames, size_t n_frames, int8_t* amp) {
+// per-symbol tone / sign of n_frames more frames of a run whose modulator stands at (T, bn) (opv-mod.cpp:228-257)
+static void symbol_codes_from(int& T, int& bn, const uint8_t* frames, size_t n_frames, int8_t* amp) {
     std::vector<uint8_t> sym(OPV_FRAME_SYMBOLS);
-    int T = 0, bn = 1;  // opv-mod.cpp:221-226: one modulator reset per run
     for (size_t f = 0; f < n_frames; ++f) {
         frame_symbols(frames + f * OPV_FRAME_BYTES, sym.data());
         for (int k = 0; k < OPV_FRAME_SYMBOLS; ++k) {
@@ -132,6 +146,11 @@ void opv_tx_symbol_codes(const uint8_t* frames, size_t n_frames, int8_t* amp) {
             bn ^= 1;
         }
     }
+}
+
+void opv_tx_symbol_codes(const uint8_t* frames, size_t n_frames, int8_t* amp) {
+    int T = 0, bn = 1;  // opv-mod.cpp:221-226: one modulator reset per run
+    symbol_codes_from(T, bn, frames, n_frames, amp);
 }
 
 void opv_tx_symbol_phases(size_t first_symbol, size_t n_symbols, double* ph1_io, double* ph2_io, double* out2) {
@@ -192,18 +211,26 @@ void opv_tx_sample_exact(double ph1_sym, double ph2_sym, int a, int i, int16_t* 
     *Q = (int16_t)(16383.0 * vq);
 }
 
-extern "C" size_t opv_tx_modulate(const uint8_t* frames, size_t n_frames, int16_t* iq) {
+// The modulator object of the reference (HDLModulator, opv-mod.cpp:219-291): the two free-running NCOs, the differential
+// sign T and the symbol parity b_n. A run is a reset, any number of frames, and - in `opv-mod` - 100 silent symbols.
+struct opv_tx_stream {
+    double ph1 = 0.0, ph2 = 0.0;
+    int T = 0, bn = 1;   // :221-226
+};
+
+// n_frames more frames of a run: samples into iq (n_frames * 2168 * 40), the state advanced past them
+static void modulate_frames(opv_tx_stream& st, const uint8_t* frames, size_t n_frames, int16_t* iq) {
+    if (n_frames == 0) return;
     const size_t nsym = n_frames * OPV_FRAME_SYMBOLS;
     // pass 1 (sequential, cheap): per-symbol active tone + sign, NCO phases at frame starts
     std::vector<int8_t> amp(nsym);  // +/-1: tone 1 active with that sign; +/-2: tone 2; 0: silent
     std::vector<FrameStart> fs(n_frames);
-    opv_tx_symbol_codes(frames, n_frames, amp.data());
+    symbol_codes_from(st.T, st.bn, frames, n_frames, amp.data());
     {
-        double ph1 = 0.0, ph2 = 0.0;
         const double inc1 = kTwoPi * (-kDev) / kFs, inc2 = kTwoPi * (+kDev) / kFs;
         for (size_t f = 0; f < n_frames; ++f) {
-            fs[f] = {ph1, ph2};
-            for (int k = 0; k < OPV_FRAME_SYMBOLS * kSps; ++k) { advance(ph1, inc1); advance(ph2, inc2); }
+            fs[f] = {st.ph1, st.ph2};
+            for (int k = 0; k < OPV_FRAME_SYMBOLS * kSps; ++k) { advance(st.ph1, inc1); advance(st.ph2, inc2); }
         }
     }
     // pass 2 (frame-parallel): samples
@@ -229,7 +256,8 @@ extern "C" size_t opv_tx_modulate(const uint8_t* frames, size_t n_frames, int16_
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 1;
     if (nt > 16) nt = 16;
-    if (nt > n_frames) nt = (unsigned)(n_frames ? n_frames : 1);
+    if (nt > n_frames) nt = (unsigned)n_frames;
+    if (nt == 1) { work(0, n_frames); return; }         // (a live source hands over one frame at a time: no thread for it)
     std::vector<std::thread> pool;
     const size_t per = (n_frames + nt - 1) / nt;
     for (unsigned t = 0; t < nt; ++t) {
@@ -237,7 +265,26 @@ extern "C" size_t opv_tx_modulate(const uint8_t* frames, size_t n_frames, int16_
         if (a < b) pool.emplace_back(work, a, b);
     }
     for (auto& th : pool) th.join();
-    const size_t body = nsym * kSps;
+}
+
+extern "C" size_t opv_tx_modulate(const uint8_t* frames, size_t n_frames, int16_t* iq) {
+    opv_tx_stream st;
+    modulate_frames(st, frames, n_frames, iq);
+    const size_t body = n_frames * (size_t)OPV_FRAME_SYMBOLS * kSps;
     std::memset(iq + 2 * body, 0, sizeof(int16_t) * 2u * 100u * kSps);
     return body + 100u * kSps;
+}
+
+extern "C" opv_tx_stream* opv_tx_stream_create(void) { return new (std::nothrow) opv_tx_stream; }
+extern "C" void opv_tx_stream_destroy(opv_tx_stream* st) { delete st; }
+extern "C" void opv_tx_stream_reset(opv_tx_stream* st) { if (st) *st = opv_tx_stream{}; }
+extern "C" size_t opv_tx_stream_frames(opv_tx_stream* st, const uint8_t* frames, size_t n_frames, int16_t* iq) {
+    if (!st || !iq || (!frames && n_frames)) return 0;
+    modulate_frames(*st, frames, n_frames, iq);
+    return n_frames * (size_t)OPV_FRAME_SYMBOLS * kSps;
+}
+extern "C" size_t opv_tx_stream_tail(int16_t* iq) {
+    if (!iq) return 0;
+    std::memset(iq, 0, sizeof(int16_t) * 2u * 100u * kSps);
+    return 100u * kSps;
 }

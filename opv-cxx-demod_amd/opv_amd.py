@@ -34,6 +34,7 @@ EXPORTS = [
     "opv_comm_destroy", "opv_gather_frames", "opv_gather_frames_all", "opv_tap_soft", "opv_tap_chunks",
     "opv_tap_offset_energies", "opv_tap_wave_info", "opv_tap_occupancy", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_bert_frames", "opv_tx_modulated_samples",
     "opv_tx_modulate", "opv_tap_tx_checkpoints", "opv_frontend_kernel", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device", "opv_tx_modulate_device_to_host",
+    "opv_tx_stream_create", "opv_tx_stream_reset", "opv_tx_stream_frames", "opv_tx_stream_tail", "opv_tx_stream_destroy", "opv_tap_tx_frame",
 ]
 
 
@@ -140,6 +141,18 @@ def lib():
         L.opv_tx_modulated_samples.argtypes = [C.c_size_t]
         L.opv_tx_modulate.restype = C.c_size_t
         L.opv_tx_modulate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.opv_tap_tx_frame.restype = None
+        L.opv_tap_tx_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.opv_tx_stream_create.restype = C.c_void_p
+        L.opv_tx_stream_create.argtypes = []
+        L.opv_tx_stream_reset.restype = None
+        L.opv_tx_stream_reset.argtypes = [C.c_void_p]
+        L.opv_tx_stream_destroy.restype = None
+        L.opv_tx_stream_destroy.argtypes = [C.c_void_p]
+        L.opv_tx_stream_frames.restype = C.c_size_t
+        L.opv_tx_stream_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.opv_tx_stream_tail.restype = C.c_size_t
+        L.opv_tx_stream_tail.argtypes = [C.c_void_p]
         L.opv_channel_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double,
                                          C.c_double, C.c_uint64]
         L.opv_resample_device.restype = C.c_long
@@ -194,6 +207,51 @@ def modulate(frames):
     w = lib().opv_tx_modulate(frames.ctypes.data, len(frames), iq.ctypes.data)
     assert w == n
     return iq
+
+
+def tx_frame_taps(frame):
+    """(randomised bytes, coded bits in encoder order, interleaved bits) of one 134-byte frame (opv_tap_tx_frame)"""
+    frame = np.ascontiguousarray(frame, np.uint8).reshape(FRAME_BYTES)
+    r, c, i = np.empty(FRAME_BYTES, np.uint8), np.empty(2144, np.uint8), np.empty(2144, np.uint8)
+    lib().opv_tap_tx_frame(frame.ctypes.data, r.ctypes.data, c.ctypes.data, i.ctypes.data)
+    return r, c, i
+
+
+class TxStream:
+    """the host modulator with its state carried from call to call (opv_tx_stream_*; reference HDLModulator,
+    src/opv-mod.cpp:219-291)"""
+
+    def __init__(self):
+        self.h = lib().opv_tx_stream_create()
+        if not self.h:
+            raise OpvError("opv_tx_stream_create failed")
+
+    def reset(self):
+        lib().opv_tx_stream_reset(self.h)
+
+    def frames(self, frames):
+        frames = np.ascontiguousarray(frames, np.uint8).reshape(-1, FRAME_BYTES)
+        iq = np.empty(2 * len(frames) * 2168 * 40, np.int16)
+        w = lib().opv_tx_stream_frames(self.h, frames.ctypes.data, len(frames), iq.ctypes.data)
+        assert w == iq.size // 2
+        return iq
+
+    @staticmethod
+    def tail():
+        iq = np.empty(2 * 4000, np.int16)
+        assert lib().opv_tx_stream_tail(iq.ctypes.data) == 4000
+        return iq
+
+    def close(self):
+        if self.h:
+            lib().opv_tx_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---------------------------------------------------------------- receiver
