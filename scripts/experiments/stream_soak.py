@@ -1,0 +1,75 @@
+"""dev soak: whole-pipeline parity on captures with the accidents a live channel has - samples dropped or repeated (the timing
+loop and the tracker's flywheel see a jump), noise bursts, deep fades, steps of the carrier, stretches of noise without a signal -
+so that the tracker walks through MISS / flywheel / lost lock / re-acquisition in many different ways. 24 streams per round
+in one context, -s and batch mode, everything the parity tests compare (frames, metrics, release symbols, tracker events as
+text, symbol counts, chunk carry, soft symbols) against the CPU oracle.
+usage: stream_soak.py [rounds=6] [seed=1]"""
+import sys
+from concurrent.futures import ProcessPoolExecutor
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT / "tests"))
+ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+S = 24
+
+
+def make(seed):
+    from oracle_lib import Oracle, accidents, impair
+    o = Oracle()
+    rng = np.random.default_rng(seed)
+    caps, notes = [], []
+    for k in range(S):
+        nf = int(rng.integers(6, 16))
+        base = o.modulate(o.bert_frames(nf, "S%d" % k, first=seed + k))
+        amp = float(rng.uniform(400, 8000))
+        x = impair(base, amp=amp, f0_hz=float(rng.uniform(-1800, 1800)), ebn0_db=float(rng.uniform(10, 22)), seed=seed * 100 + k)
+        x, note = accidents(x, rng, amp)
+        caps.append(x)
+        notes.append(note)
+    return caps, notes
+
+
+def oracle_one(args):
+    from oracle_lib import Oracle
+    x, streaming = args
+    return Oracle().receive(x, streaming=streaming)
+
+
+def main():
+    from amd_lib import load
+    import test_gpu_parity as T
+    amd = load()
+    runs = bad = frames = edge = 0
+    kinds = {}
+    for r in range(ROUNDS):
+        caps, notes = make(SEED * 1000 + r)
+        nmax = max(c.size // 2 for c in caps)
+        for streaming in (True, False):
+            d = amd.Demod(S, max_samples=nmax + 64, streaming=streaming)
+            got = d.receive(caps)
+            d.close()
+            with ProcessPoolExecutor(12) as ex:
+                exp = list(ex.map(oracle_one, [(c, streaming) for c in caps]))
+            for k in range(S):
+                runs += 1
+                frames += len(exp[k]["frames"])
+                for v in exp[k]["events"]["kind"]:
+                    kinds[int(v)] = kinds.get(int(v), 0) + 1
+                if got[k]["state"].edge_ties:            # a one-tap window next to exact zeros: reported, not reproducible
+                    edge += 1
+                    continue
+                try:
+                    T.check_stream(amd, got[k], exp[k], f"soak r{r} s{k} streaming={streaming} [{notes[k]}]", offset_ties=None)
+                except AssertionError as e:
+                    bad += 1
+                    print("MISMATCH", r, k, streaming, notes[k], str(e)[:300], flush=True)
+        print(f"round {r}: {runs} stream runs, {frames} frames, {bad} mismatches, {edge} skipped for edge_ties, tracker event kinds so far {dict(sorted(kinds.items()))}", flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -435,6 +435,43 @@ def impair(iq, amp=2000.0, f0_hz=0.0, ebn0_db=None, seed=1, full_scale=16383.0):
     return out
 
 
+def accidents(iq, rng, amp, n_max=4):
+    """What a live channel does to a capture besides noise (a test INPUT generator, like impair): 1..n_max of - samples
+    dropped or repeated (the timing loop and the tracker's flywheel see a jump), a burst of strong noise, a deep fade, a
+    step of the carrier, a stretch of weak noise without a signal (never an exact zero run: that class is covered by the
+    silence tests). Returns (int16 IQ, a note naming the accidents)."""
+    iq = _iq(iq)
+    z = iq[0::2].astype(np.float64) + 1j * iq[1::2].astype(np.float64)
+    note = []
+    for _ in range(int(rng.integers(1, n_max + 1))):
+        kind = str(rng.choice(["drop", "dup", "burst", "fade", "fstep", "noisegap"]))
+        at = int(rng.integers(1000, z.size - 1000))
+        if kind == "drop":
+            m = int(rng.integers(1, 3000))
+            z = np.concatenate([z[:at], z[at + m:]])
+        elif kind == "dup":
+            m = int(rng.integers(1, 3000))
+            z = np.concatenate([z[:at], z[at - min(m, at):at], z[at:]])
+        elif kind == "burst":
+            e = min(z.size, at + int(rng.integers(1000, 200000)))
+            z[at:e] += amp * 30 * (rng.standard_normal(e - at) + 1j * rng.standard_normal(e - at))
+        elif kind == "fade":
+            e = min(z.size, at + int(rng.integers(1000, 300000)))
+            z[at:e] *= 0.03
+        elif kind == "fstep":
+            df = float(rng.uniform(-500, 500))
+            z[at:] *= np.exp(2j * np.pi * df * np.arange(z.size - at) / 2168000.0)
+        else:
+            e = min(z.size, at + int(rng.integers(1000, 300000)))
+            z[at:e] = 3.0 * (rng.standard_normal(e - at) + 1j * rng.standard_normal(e - at)) + (0.4 + 0.3j)
+        note.append(kind)
+    out = np.empty(2 * z.size, np.int16)
+    out[0::2] = np.clip(np.rint(z.real), -32768, 32767).astype(np.int16)
+    out[1::2] = np.clip(np.rint(z.imag), -32768, 32767).astype(np.int16)
+    out[0::2][(out[0::2] == 0) & (out[1::2] == 0)] = 1     # (a fade over a stretch of weak noise rounds to exact zeros otherwise)
+    return out, "+".join(note)
+
+
 def resample_clock(iq, ppm):
     """Sample-clock error for the timing loop: the capture as an ADC running `ppm`
     parts per million fast would have taken it (linear interpolation, round to nearest). A test

@@ -1171,6 +1171,32 @@ def test_clock_rate_error_and_random_channels_fuzz(amd, oracle, iq10, iq100, see
             assert len(kinds) >= 8, kinds        # the clock error really moved the chunk grid (leftovers 18..50)
 
 
+def test_channel_accidents(amd, oracle):
+    """Captures with the accidents of a live channel (tests/oracle_lib.py::accidents: dropped / repeated samples, noise
+    bursts, deep fades, carrier steps, stretches without a signal) on top of offset and AWGN: the tracker goes through
+    MISS, flywheel, lost lock and re-acquisition, the timing loop through jumps - everything still equals the oracle, in -s
+    and batch mode. (scripts/experiments/stream_soak.py is the long form: 24 streams a round.)"""
+    from oracle_lib import accidents
+    rng = np.random.default_rng(20261004)
+    caps = []
+    for k in range(8):
+        base = oracle.modulate(oracle.bert_frames(int(rng.integers(6, 12)), "A%d" % k, first=40 * k))
+        amp = float(rng.uniform(400, 8000))
+        x = impair(base, amp=amp, f0_hz=float(rng.uniform(-1800, 1800)), ebn0_db=float(rng.uniform(10, 22)), seed=900 + k)
+        caps.append(accidents(x, rng, amp)[0])
+    nmax = max(c.size // 2 for c in caps)
+    kinds = set()
+    for streaming in (True, False):
+        d = amd.Demod(len(caps), max_samples=nmax + 64, streaming=streaming)
+        got = d.receive(caps)
+        d.close()
+        for k, x in enumerate(caps):
+            exp = oracle.receive(x, streaming=streaming)
+            check_stream(amd, got[k], exp, f"accidents {k} streaming={streaming}", offset_ties=None)
+            kinds.update(int(v) for v in exp["events"]["kind"])
+    assert {1, 2, 3, 4, 5} <= kinds, kinds               # acquisitions, locks, sync OK, misses and a lost lock all occurred
+
+
 def test_four_streams_per_wave_mapping(amd, oracle, iq10, iq100):
     """k_msk_frontend_x4 (four streams per wavefront, the mapping the shim picks from 2049 streams) on
     the cases that exercise its per-row machinery: rows with different chunk schedules (clock error,
