@@ -320,6 +320,7 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
 
 extern "C" void opv_destroy(opv_ctx* c) {
     if (!c) return;
+    (void)hipSetDevice(c->cfg.device);       // (a host with contexts on several GPUs: free on the context's own device)
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& e : c->in_ev)
