@@ -176,6 +176,7 @@ struct opv_ctx {
 
     int refresh() {
         if (mirror_valid) return OPV_OK;
+        HIPCHK(hipSetDevice(cfg.device));       // (every pop / state / tap comes through here: a host with contexts on several GPUs)
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipMemcpy(mirror.data(), d_streams, sizeof(OpvStream) * n_streams, hipMemcpyDeviceToHost));
         mirror_valid = true;
