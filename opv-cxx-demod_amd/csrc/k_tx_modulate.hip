@@ -20,6 +20,15 @@
 // Exactness: device sincos and glibc agree to ~1 ulp, so 16383*x can only truncate differently when it lies within ~1e-11
 // of an integer. Such samples (none in practice) are reported in a small list and re-evaluated by the host with libm, so
 // the result is identical to `opv-mod` by construction, not by luck.
+// One place is not "in practice none": the FLAT TOPS. A symbol lasts a quarter period of either tone, so at every symbol
+// start sin or cos of each NCO sits at +/-1 up to the phase's accumulated rounding drift eps (6.74e-12 rad per frame, from
+// the recurrence itself: data-independent and monotone), i.e. at 1 - eps^2/2 - and 16383 x truncates to 16383 only if the
+// library returns exactly 1.0. glibc does while eps^2/2 < 2^-54 (eps < 1.05e-8: 1563 frames into a run) and returns
+// 1 - 2^-53 from there on (16382). The kernel therefore decides flat tops by the symbol index, not by its own sincos:
+// 16383 before `flat_lo` (eps < 0.90e-8: within 0.37 ulp of 1.0), 16382 from `flat_hi` on (eps > 1.25e-8: 0.70 ulp below),
+// and in the ~500 frames between by a bit per symbol and tone that the host made with libm itself (opv_capi.hip; once per
+// context and run length). tests/test_capi_and_host.py::test_flat_top_zones_hold_for_this_libm scans both zones on the
+// host's libm.
 //
 // Roofline: HBM write, 4 B/sample (a 1000-frame run: 347 MB); the phase table adds 16 B/symbol of reads (35 MB).
 #include <hip/hip_runtime.h>
@@ -165,7 +174,9 @@ extern "C" __global__ __launch_bounds__(64) void k_tx_modulate(const uint8_t* __
                                                                 const double2* __restrict__ phases, uint64_t nsym,
                                                                 uint64_t nsym_total, int* __restrict__ out,
                                                                 uint32_t* __restrict__ amb_count,
-                                                                uint64_t* __restrict__ amb_list, uint32_t amb_cap) {
+                                                                uint64_t* __restrict__ amb_list, uint32_t amb_cap,
+                                                                uint64_t flat_lo, uint64_t flat_hi,
+                                                                const uint8_t* __restrict__ flat_bits) {
     __shared__ __attribute__((aligned(16))) int stage[64 * OPV_SPS];
     const uint64_t sym0 = (uint64_t)blockIdx.x * 64u;
     const uint64_t sym = sym0 + threadIdx.x;
@@ -191,13 +202,23 @@ extern "C" __global__ __launch_bounds__(64) void k_tx_modulate(const uint8_t* __
             double sn, cs;
             sincos(tone1 ? ph1 : ph2, &sn, &cs);
             const double vi = 16383.0 * (sgn * sn), vq = 16383.0 * (sgn * cs);  // opv-mod.cpp:268-272
-            const int I = (int)vi, Q = (int)vq;                                   // truncation toward zero
+            int I = (int)vi, Q = (int)vq;                                         // truncation toward zero
+            // a flat top (see the file comment): |sin| or |cos| = 1 - eps^2/2; whether libm's value IS 1.0 is a function
+            // of the symbol index
+            const bool top_i = fabs(vi) > 16382.5, top_q = fabs(vq) > 16382.5;
+            if (top_i | top_q) {
+                int mag = 16383;
+                if (sym >= flat_hi) mag = 16382;
+                else if (sym >= flat_lo) mag = ((flat_bits[sym - flat_lo] >> (tone1 ? 0 : 1)) & 1u) ? 16383 : 16382;
+                if (top_i) I = vi < 0.0 ? -mag : mag;
+                else Q = vq < 0.0 ? -mag : mag;
+            }
             mine[i] = (I & 0xFFFF) | (Q << 16);
             // Could libm's value truncate differently? Only if v sits within the two libraries' ~1e-11
             // disagreement of a NON-ZERO integer without being exactly on it (|v| < 1 truncates to 0
-            // from either side; sin/cos == +/-1.0 exactly gives exactly +/-16383 in both libraries).
+            // from either side); the flat tops are decided above.
             const double ri = rint(vi), rq = rint(vq);
-            if ((ri != 0.0 && vi != ri && fabs(vi - ri) < 1e-9) || (rq != 0.0 && vq != rq && fabs(vq - rq) < 1e-9)) {
+            if ((!top_i && ri != 0.0 && vi != ri && fabs(vi - ri) < 1e-9) || (!top_q && rq != 0.0 && vq != rq && fabs(vq - rq) < 1e-9)) {
                 const uint32_t k = atomicAdd(amb_count, 1u);
                 if (k < amb_cap) amb_list[k] = sym * OPV_SPS + (uint64_t)i;
             }

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/opv_demod.h"
@@ -37,7 +38,8 @@ extern "C" __global__ void k_resample_clock(const int*, uint64_t, int*, uint64_t
 extern "C" __global__ void k_tx_encode(const uint8_t*, uint32_t, uint8_t*, uint8_t*);
 extern "C" __global__ void k_tx_scan_frames(uint8_t*, uint32_t);
 extern "C" __global__ void k_tx_expand_phases(const double2*, uint32_t, uint64_t, uint64_t, double2*);
-extern "C" __global__ void k_tx_modulate(const uint8_t*, const uint8_t*, const double2*, uint64_t, uint64_t, int*, uint32_t*, uint64_t*, uint32_t);
+extern "C" __global__ void k_tx_modulate(const uint8_t*, const uint8_t*, const double2*, uint64_t, uint64_t, int*, uint32_t*, uint64_t*, uint32_t,
+                                         uint64_t, uint64_t, const uint8_t*);
 
 namespace {
 
@@ -157,6 +159,10 @@ struct opv_ctx {
     size_t tx_frames_cap = 0;            // frames the three scratch buffers hold
     uint32_t* d_tx_cnt = nullptr;        // ambiguous-sample counter + list
     uint64_t* d_tx_list = nullptr;
+    // flat tops (k_tx_modulate.hip): symbols [tx_flat_lo, tx_flat_hi) are decided by a bit per tone made with the host's libm;
+    // d_tx_flat holds them for [tx_flat_lo, tx_flat_have)
+    uint8_t* d_tx_flat = nullptr;
+    uint64_t tx_flat_lo = ~0ull, tx_flat_hi = ~0ull, tx_flat_have = 0, tx_flat_cap = 0;
     const char* last_frontend = "";   // kernel the last opv_process launched for the front-end (opv_frontend_kernel)
     int frontend = 0;  // 0: by stream count, 1: one wave per stream, 4: four streams per wave, -1 / -2: see opv_set_frontend
     bool timing = false;
@@ -334,7 +340,7 @@ extern "C" void opv_destroy(opv_ctx* c) {
     }
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_fscale, c->d_counts, c->d_tx_phases, c->d_offs_wtab, c->d_tx_ckpt, c->d_tx_frames, c->d_tx_codes, c->d_tx_fpar, c->d_tx_cnt, c->d_tx_list};
+    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_fscale, c->d_counts, c->d_tx_phases, c->d_offs_wtab, c->d_tx_ckpt, c->d_tx_frames, c->d_tx_codes, c->d_tx_fpar, c->d_tx_cnt, c->d_tx_list, c->d_tx_flat};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -885,6 +891,63 @@ extern "C" long opv_tx_modulate_device(opv_ctx* c, const uint8_t* frames, size_t
         HIPCHK(hipGetLastError());
         c->tx_phases_have = nsym;
     }
+    // ---- flat tops: the zone limits from the checkpoint sequence (the drift is monotone), the bits in between from libm
+    if (c->tx_flat_hi == ~0ull) {                            // (both limits found: final - the sequence is data-independent)
+        const size_t n_ck = (nsym + OPV_TX_CKPT_SYMS - 1) / OPV_TX_CKPT_SYMS;
+        auto drift = [](size_t j) {                          // distance of checkpoint j's phases from a multiple of pi/2
+            double p[2];
+            opv_tx_checkpoint_range(j, 1, p);
+            const double q = 1.57079632679489661923;
+            const double d1 = std::fabs(p[0] - std::nearbyint(p[0] / q) * q), d2 = std::fabs(p[1] - std::nearbyint(p[1] / q) * q);
+            return d1 > d2 ? d1 : d2;
+        };
+        auto first_at = [&](double thr) -> size_t {         // smallest checkpoint index with drift >= thr, n_ck if none
+            size_t lo = 0, hi = n_ck;
+            while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (drift(mid) >= thr) hi = mid; else lo = mid + 1; }
+            return lo;
+        };
+        const size_t j_lo = n_ck ? first_at(0.90e-8) : 0, j_hi = n_ck ? first_at(1.25e-8) : 0;
+        c->tx_flat_lo = j_lo >= n_ck ? ~0ull : (uint64_t)(j_lo ? j_lo - 1 : 0) * OPV_TX_CKPT_SYMS;
+        c->tx_flat_hi = j_hi >= n_ck ? ~0ull : (uint64_t)(j_hi + 1) * OPV_TX_CKPT_SYMS;
+    }
+    if (c->tx_flat_lo != ~0ull && nsym > c->tx_flat_lo) {
+        const uint64_t want = c->tx_flat_hi < (uint64_t)nsym ? c->tx_flat_hi : (uint64_t)nsym;   // bits for [flat_lo, want)
+        if (c->tx_flat_have < want) {
+            const size_t cnt = (size_t)(want - c->tx_flat_lo);
+            if (c->tx_flat_cap < cnt) {
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (c->d_tx_flat) HIPCHK(hipFree(c->d_tx_flat));
+                c->d_tx_flat = nullptr;
+                c->tx_flat_cap = 0;
+                c->tx_flat_have = 0;
+                HIPCHK(hipMalloc(&c->d_tx_flat, cnt));
+                c->tx_flat_cap = cnt;
+            }
+            std::vector<double> ph(2 * cnt);
+            HIPCHK(hipStreamSynchronize(c->stream));                        // the expansion above
+            HIPCHK(hipMemcpy(ph.data(), c->d_tx_phases + 2 * c->tx_flat_lo, sizeof(double) * 2 * cnt, hipMemcpyDeviceToHost));
+            std::vector<uint8_t> bits(cnt);
+            auto work = [&](size_t a, size_t b) {
+                for (size_t k = a; k < b; ++k) {
+                    const double p1 = ph[2 * k], p2 = ph[2 * k + 1];
+                    const bool e1 = std::fabs(std::sin(p1)) == 1.0 || std::fabs(std::cos(p1)) == 1.0;
+                    const bool e2 = std::fabs(std::sin(p2)) == 1.0 || std::fabs(std::cos(p2)) == 1.0;
+                    bits[k] = (uint8_t)((e1 ? 1 : 0) | (e2 ? 2 : 0));
+                }
+            };
+            unsigned nt = std::thread::hardware_concurrency();
+            if (nt == 0) nt = 1;
+            if (nt > 16) nt = 16;
+            if (cnt < 65536) nt = 1;
+            std::vector<std::thread> pool;
+            const size_t per = (cnt + nt - 1) / nt;
+            for (unsigned t = 1; t < nt; ++t) { const size_t a = t * per, b = a + per < cnt ? a + per : cnt; if (a < b) pool.emplace_back(work, a, b); }
+            work(0, per < cnt ? per : cnt);
+            for (auto& th : pool) th.join();
+            HIPCHK(hipMemcpy(c->d_tx_flat, bits.data(), cnt, hipMemcpyHostToDevice));
+            c->tx_flat_have = want;
+        }
+    }
     // ---- scratch (grow-only)
     if (c->tx_frames_cap < n_frames || !c->d_tx_cnt) {
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -908,7 +971,8 @@ extern "C" long opv_tx_modulate_device(opv_ctx* c, const uint8_t* frames, size_t
         k_tx_scan_frames<<<1, 1024, 0, c->stream>>>(c->d_tx_fpar, (uint32_t)n_frames);
     }
     k_tx_modulate<<<(unsigned)((nsym_total + 63) / 64), 64, 0, c->stream>>>(c->d_tx_codes, c->d_tx_fpar, (const double2*)c->d_tx_phases, nsym,
-                                                                          nsym_total, (int*)d_iq_out, c->d_tx_cnt, c->d_tx_list, kAmbCap);
+                                                                          nsym_total, (int*)d_iq_out, c->d_tx_cnt, c->d_tx_list, kAmbCap,
+                                                                          c->tx_flat_lo, c->tx_flat_hi, c->d_tx_flat);
     HIPCHK(hipGetLastError());
     uint32_t n_amb = 0;
     HIPCHK(hipMemcpyAsync(&n_amb, c->d_tx_cnt, sizeof n_amb, hipMemcpyDeviceToHost, c->stream));

@@ -302,3 +302,24 @@ def test_opv_mod_raw_mode_writes_as_frames_arrive(amd):
     assert p.wait() == 0
     assert got == subprocess.run([ours, "-R"], input=b"".join(fr), capture_output=True, timeout=120).stdout
     assert np.array_equal(np.frombuffer(got, np.int16), amd.modulate(np.frombuffer(b"".join(fr), np.uint8).reshape(3, 134)))
+
+
+def test_flat_top_zones_hold_for_this_libm():
+    """k_tx_modulate.hip decides the flat tops of the NCOs (sin or cos = 1 - eps^2/2 at every symbol start) by the symbol
+    index: exactly +/-1.0 while the phase drift eps < 0.90e-8, below 1.0 from 1.25e-8 on, libm's own answer in between.
+    That is a statement about THIS machine's libm (the one the host modulator and the reference use): scanned here, both
+    zones, both functions, all four quadrant points."""
+    libm = C.CDLL("libm.so.6")
+    for f in (libm.sin, libm.cos):
+        f.restype = C.c_double
+        f.argtypes = [C.c_double]
+    pi = 3.14159265358979323846
+    tops = [(libm.sin, pi / 2), (libm.sin, -pi / 2), (libm.cos, 0.0), (libm.cos, pi), (libm.cos, -pi)]
+    rng = np.random.default_rng(5)
+    exact = np.concatenate([np.linspace(0.0, 0.90e-8, 4001), rng.uniform(0.0, 0.90e-8, 4000)])
+    below = np.concatenate([np.linspace(1.25e-8, 4e-8, 4001), 10.0 ** rng.uniform(np.log10(1.25e-8), -5.0, 4000)])
+    for f, x0 in tops:
+        for e in exact:
+            assert abs(f(x0 + e)) == 1.0 and abs(f(x0 - e)) == 1.0, (x0, e)
+        for e in below:
+            assert abs(f(x0 + e)) < 1.0 and abs(f(x0 - e)) < 1.0, (x0, e)

@@ -604,6 +604,24 @@ def test_device_transmit_chain_lengths_order_and_table_end(amd, golden):
     assert r.stdout.strip().splitlines()[-1] == pins["100"]["sha256"]
 
 
+def test_device_transmit_chain_past_the_flat_top_flip(amd):
+    """Runs longer than 1563 frames: from there on glibc's sin / cos at the flat tops of the NCOs (one per symbol start and
+    tone) is 1 - 2^-53, not 1.0, and 16383 x truncates to 16382 (k_tx_modulate.hip; round 3's first build flagged every such
+    sample as ambiguous and gave up from ~1570 frames). One context, lengths in an order that grows and shrinks the cached
+    zone bits; every run equals the host modulator (= opv-mod, by its sha256 pins) sample for sample, nothing patched."""
+    import torch
+    rng = np.random.default_rng(91)
+    fr = rng.integers(0, 256, (2600, 134), dtype=np.uint8)
+    d = amd.Demod(1, max_samples=1 << 16)
+    for n in (1450, 2600, 1700, 900):
+        ns = amd.lib().opv_tx_modulated_samples(n)
+        out = torch.empty(2 * ns, dtype=torch.int16, device="cuda")
+        assert d.modulate_device(fr[:n], out.data_ptr()) == 0, n
+        assert np.array_equal(out.cpu().numpy(), amd.modulate(fr[:n])), n
+        del out
+    d.close()
+
+
 def test_opv_mod_cli_on_the_gpu(amd, golden):
     """`bin/opv-mod -G 0`: the reference's modulator CLI with the transmit chain on the device - BERT and raw mode, the same
     bytes as the reference `opv-mod` (sha256 pins) / as the host chain."""
