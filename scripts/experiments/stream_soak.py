@@ -3,7 +3,7 @@ loop and the tracker's flywheel see a jump), noise bursts, deep fades, steps of 
 so that the tracker walks through MISS / flywheel / lost lock / re-acquisition in many different ways. 24 streams per round
 in one context, -s and batch mode, everything the parity tests compare (frames, metrics, release symbols, tracker events as
 text, symbol counts, chunk carry, soft symbols) against the CPU oracle.
-usage: stream_soak.py [rounds=6] [seed=1]"""
+usage: stream_soak.py [rounds=6] [seed=1] [streams=24]   (from 513 streams the shim launches k_msk_frontend_rb_wg4, from 2049 _x4)"""
 import sys
 from concurrent.futures import ProcessPoolExecutor
 from pathlib import Path
@@ -14,7 +14,7 @@ ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "tests"))
 ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-S = 24
+S = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 
 
 def make(seed):
@@ -51,6 +51,7 @@ def main():
         for streaming in (True, False):
             d = amd.Demod(S, max_samples=nmax + 64, streaming=streaming)
             got = d.receive(caps)
+            kernel = d.frontend_kernel()
             d.close()
             with ProcessPoolExecutor(12) as ex:
                 exp = list(ex.map(oracle_one, [(c, streaming) for c in caps]))
@@ -67,7 +68,7 @@ def main():
                 except AssertionError as e:
                     bad += 1
                     print("MISMATCH", r, k, streaming, notes[k], str(e)[:300], flush=True)
-        print(f"round {r}: {runs} stream runs, {frames} frames, {bad} mismatches, {edge} skipped for edge_ties, tracker event kinds so far {dict(sorted(kinds.items()))}", flush=True)
+        print(f"round {r}: kernel {kernel},  {runs} stream runs, {frames} frames, {bad} mismatches, {edge} skipped for edge_ties, tracker event kinds so far {dict(sorted(kinds.items()))}", flush=True)
     sys.exit(1 if bad else 0)
 
 
