@@ -316,6 +316,10 @@ int main(int argc, char** argv) {
         // one read later when it is not (a file, a fast pipe): the next block is then read and copied to the device while the
         // kernels of this round run, instead of the host waiting for them first.
         bool pending = false;
+        // what a round may take in before it is processed: eight chunks, or what the staging buffer holds besides the carry of
+        // the last chunk, a chunk of slack and one more read (a small --capacity-sec: chunk by chunk as before)
+        const uint64_t hold = 2ull * OPV_CHUNK_SAMPLES + buf.size() / 4;
+        const uint64_t round_cap = cfg.max_samples > hold ? std::min<uint64_t>(8ull * OPV_CHUNK_SAMPLES, cfg.max_samples - hold) : 0;
         auto stdin_has_data = [] { pollfd p{STDIN_FILENO, POLLIN, 0}; return poll(&p, 1, 0) > 0 && (p.revents & (POLLIN | POLLHUP)); };
         for (;;) {
             blk.clear();
@@ -328,7 +332,7 @@ int main(int argc, char** argv) {
             if (since >= OPV_CHUNK_SAMPLES - 64) {  // a chunk boundary may have been crossed
                 // a backlog on stdin (a file, a fast pipe): up to eight chunks go into one round - the launches and the
                 // hand-shake of a round are paid once; a live source never has a backlog and is served chunk by chunk
-                if (since < 8ull * OPV_CHUNK_SAMPLES && stdin_has_data()) continue;
+                if (since < round_cap && stdin_has_data()) continue;
                 if (opv_process(ctx) < 0) return die("opv_process");
                 if (stdin_has_data()) pending = true;
                 else if (sink.drain() < 0) return die("drain");

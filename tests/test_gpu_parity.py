@@ -1136,6 +1136,20 @@ def test_host_cli_process_contract(amd, golden, iq10):
     assert "Demodulated 21780 symbols, final AFC offset: " in err                  # the reference's count (:462, :1173)
 
 
+def test_host_cli_small_staging_buffer_and_a_backlog(amd, oracle, iq100):
+    """bin/opv-demod takes up to eight chunks per round when stdin has a backlog - but never more than its staging buffer
+    holds: with --capacity-sec 0.15 (3.75 chunks) and with 0.09 (2.2 chunks: no batching at all) a 30-frame capture read from
+    a file still comes out whole, frame for frame the oracle's."""
+    import subprocess
+    dem = str(ROOT / "opv-cxx-demod_amd" / "bin" / "opv-demod")
+    x = iq100[: 2 * 86720 * 30]
+    exp = oracle.receive(x, streaming=True, want_soft=False)["frames"]
+    for cap in ("0.15", "0.09", "2"):
+        p = subprocess.run([dem, "-s", "-r", "-q", "--capacity-sec", cap], input=x.tobytes(), capture_output=True, timeout=300)
+        assert p.returncode == 0, (cap, p.stderr[-300:])
+        assert p.stdout == exp.tobytes(), cap
+
+
 def test_reference_makefile_targets_with_our_binaries():
     """The reference's own (and only) tests, run on the drop-in binaries: `make test` (Makefile:23-25: opv-mod -S W5NYV
     -B 5 | opv-demod -s, grep Station|Token|Summary) and `make test-raw` (Makefile:28-33: three hand-built frames through
