@@ -1229,6 +1229,36 @@ def test_channel_accidents(amd, oracle):
     assert {1, 2, 3, 4, 5} <= kinds, kinds               # acquisitions, locks, sync OK, misses and a lost lock all occurred
 
 
+@pytest.mark.parametrize("order", [[0, 4, 1, -1, 4, 0], [4, 0, -2, 1, 4, 0]])
+def test_mapping_switched_between_rounds(amd, oracle, order):
+    """opv_set_frontend between two opv_process calls of running streams: every mapping reads and leaves the same per-stream
+    carry (OpvStream), so a context may change its mapping at any round boundary - six noisy streams pushed in six pieces, a
+    different kernel for each piece, the result the oracle's."""
+    rng = np.random.default_rng(3)
+    caps = [impair(oracle.modulate(oracle.bert_frames(10, "M%d" % k, first=k)), amp=float(rng.uniform(800, 6000)),
+                   f0_hz=float(rng.uniform(-1500, 1500)), ebn0_db=float(rng.uniform(12, 20)), seed=50 + k) for k in range(6)]
+    n = caps[0].size // 2
+    cuts = [0, n // 6, n // 3, n // 2, 2 * n // 3, 5 * n // 6, n]
+    d = amd.Demod(6, max_samples=n + 64, streaming=True)
+    for i, m in enumerate(order):
+        d.set_frontend(m)
+        for k in range(6):
+            d.push(k, caps[k][2 * cuts[i]: 2 * cuts[i + 1]])
+        if i == len(order) - 1:
+            for k in range(6):
+                d.flush(k)
+        d.process()
+        d.sync()
+    for k in range(6):
+        fr, meta = d.pop_frames(k)
+        e = oracle.receive(caps[k], streaming=True)
+        assert np.array_equal(fr, e["frames"]) and np.array_equal(meta["viterbi_metric"], e["metrics"]), k
+        assert np.array_equal(meta["release_symbol"], e["frame_sym"]) and d.state(k).total_symbols == e["n_soft"], k
+        a, _ = soft_err(d.soft(k), e["soft"])
+        assert a < SOFT_TIGHT, (k, a)
+    d.close()
+
+
 def test_four_streams_per_wave_mapping(amd, oracle, iq10, iq100):
     """k_msk_frontend_x4 (four streams per wavefront, the mapping the shim picks from 2049 streams) on
     the cases that exercise its per-row machinery: rows with different chunk schedules (clock error,
