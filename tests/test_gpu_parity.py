@@ -421,6 +421,54 @@ def test_errors_are_loud(amd):
     d.close()
 
 
+def test_api_misuse_returns_errors_and_leaves_the_context_usable(amd):
+    """Null pointers, stream indices out of range, absurd sizes, unaligned device pointers, missing communicators through
+    every entry point of include/opv_demod.h that takes a context: a negative code (or 0 for the documented no-ops: empty
+    pushes, empty pops), never a crash, and the context still processes afterwards."""
+    import ctypes as C
+    L = amd.lib()
+    ctx = C.c_void_p()
+    cfg = amd.Cfg()
+    cfg.streaming, cfg.afc_alpha, cfg.max_samples, cfg.device = 1, 0.001, 100000, 0
+    for args in ((None, 1, C.byref(cfg)), (C.byref(ctx), 1, None), (C.byref(ctx), 0, C.byref(cfg)), (C.byref(ctx), -5, C.byref(cfg))):
+        assert L.opv_create(*args) < 0
+    far = amd.Cfg()
+    far.streaming, far.afc_alpha, far.max_samples, far.device = 1, 0.001, 100000, 99
+    assert L.opv_create(C.byref(ctx), 1, C.byref(far)) == -2                       # OPV_ENODEV
+    assert L.opv_create(C.byref(ctx), 3, C.byref(cfg)) == 0
+    iq = np.zeros(2000, np.int16)
+    p = iq.ctypes.data
+    bad = [("opv_push_iq", (None, 0, p, 10)), ("opv_push_iq", (ctx, 7, p, 10)), ("opv_push_iq", (ctx, -1, p, 10)), ("opv_push_iq", (ctx, 0, None, 10)),
+           ("opv_push_iq", (ctx, 0, p, 10 ** 9)), ("opv_push_iq_batch", (ctx, -1, None, None, None)), ("opv_push_iq_batch", (ctx, 2, None, None, None)),
+           ("opv_flush", (ctx, 9)), ("opv_flush", (None, 0)), ("opv_attach_device_iq", (ctx, 0, C.c_void_p(3), 100, 1)),
+           ("opv_attach_device_iq", (ctx, 0, None, 100, 1)), ("opv_process", (None,)), ("opv_sync", (None,)), ("opv_set_frontend", (ctx, 3)),
+           ("opv_set_frontend", (None, 1)), ("opv_reset_stream", (ctx, 5)), ("opv_pop_frames", (ctx, 9, p, 1, None)), ("opv_get_state", (ctx, 0, None)),
+           ("opv_get_state", (ctx, 4, p)), ("opv_tap_offset_energies", (ctx, 0, None)), ("opv_tap_wave_info", (ctx, 8, p)), ("opv_tap_occupancy", (ctx, None)),
+           ("opv_decode_payloads", (ctx, None, 3, p, p, None, None, None)), ("opv_channel_device", (ctx, None, None, 16, C.c_double(1), C.c_double(0), C.c_double(0), 1)),
+           ("opv_channel_device", (ctx, C.c_void_p(16), C.c_void_p(32), 3, C.c_double(1), C.c_double(0), C.c_double(0), 1)),
+           ("opv_resample_device", (ctx, None, 10, None, 10, C.c_double(0))), ("opv_tx_modulate_device", (ctx, None, 3, None)),
+           ("opv_tx_modulate_device", (ctx, p, 1, C.c_void_p(4))), ("opv_tx_modulate_device_to_host", (ctx, None, 0, None)),
+           ("opv_gather_frames", (ctx, None, 0, None, None)), ("opv_gather_frames", (None, None, 0, None, None)), ("opv_gather_frames_all", (None, None, 0, 0, None, None)),
+           ("opv_comm_init", (None, 1, 0, None, 0)), ("opv_comm_init_all", (None, 0, None)), ("opv_comm_unique_id", (None,)), ("opv_kernel_times", (ctx, None)),
+           ("opv_enable_timing", (None, 1))]
+    noop = [("opv_push_iq", (ctx, 0, p, 0)), ("opv_push_iq", (ctx, 0, None, 0)), ("opv_push_iq_batch", (ctx, 0, None, None, None)),
+            ("opv_pop_frames", (ctx, 0, None, 10, None)), ("opv_pop_frames", (ctx, 0, p, 0, None)), ("opv_pop_events", (ctx, 0, None, 5)),
+            ("opv_tap_soft", (ctx, 0, 0, None, 10)), ("opv_decode_payloads", (ctx, p, 0, p, p, None, None, None))]
+    for group, want_error in ((bad, True), (noop, False)):
+        for name, args in group:
+            f = getattr(L, name)
+            saved, f.argtypes = f.argtypes, None
+            saved_res, f.restype = f.restype, C.c_int
+            try:
+                r = f(*[C.c_uint64(a) if isinstance(a, int) and a >= 2 ** 31 else a for a in args])
+            finally:
+                f.argtypes, f.restype = saved, saved_res
+            assert (r < 0) if want_error else (r == 0), (name, args, r)
+    assert L.opv_push_iq(ctx, 0, p, 100) == 0 and L.opv_process(ctx) == 0 and L.opv_sync(ctx) == 0
+    L.opv_destroy(ctx)
+    L.opv_destroy(None)
+
+
 # ------------------------------------------------------------------ full-size cases
 def test_config1_full_size_vs_reference_hashes(amd, golden):
     """BASELINE configs[1] at full size: 1000 clean frames, one stream. The input is the product's
