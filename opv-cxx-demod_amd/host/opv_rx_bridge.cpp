@@ -64,7 +64,17 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "-a") && i + 1 < argc) afc = atof(argv[++i]);
         else if (!strcmp(argv[i], "--device") && i + 1 < argc) device = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--devices") && i + 1 < argc) {
-            for (const char* p = argv[++i]; *p;) { devices.push_back((int)strtol(p, (char**)&p, 10)); if (*p == ',') ++p; }
+            for (const char* p = argv[++i]; *p;) {
+                char* end = nullptr;
+                const long v = strtol(p, &end, 10);
+                if (end == p || v < 0 || v > 1023 || (*end != ',' && *end != 0)) {     // ("x,y", "0,,1", "-1": not a list of ordinals)
+                    fprintf(stderr, "opv-rx-bridge: --devices takes a comma-separated list of HIP device ordinals, got '%s'\n", argv[i]);
+                    return 2;
+                }
+                devices.push_back((int)v);
+                p = *end == ',' ? end + 1 : end;
+            }
+            if (devices.empty()) { fprintf(stderr, "opv-rx-bridge: --devices takes a comma-separated list of HIP device ordinals\n"); return 2; }
         } else if (!strcmp(argv[i], "--gather")) gather = true;
         else if (!strcmp(argv[i], "-q")) quiet = true;
         else if (!strcmp(argv[i], "-h")) {

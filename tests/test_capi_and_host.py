@@ -323,3 +323,13 @@ def test_flat_top_zones_hold_for_this_libm():
             assert abs(f(x0 + e)) == 1.0 and abs(f(x0 - e)) == 1.0, (x0, e)
         for e in below:
             assert abs(f(x0 + e)) < 1.0 and abs(f(x0 - e)) < 1.0, (x0, e)
+
+
+def test_rx_bridge_rejects_a_malformed_device_list(amd):
+    """`opv-rx-bridge --devices x,y` used to spin forever (strtol does not advance on a non-number); every malformed list is
+    refused with a message and exit status 2 before anything touches a GPU."""
+    import subprocess
+    b = str(ROOT / "opv-cxx-demod_amd" / "bin" / "opv-rx-bridge")
+    for bad in ("x,y", "0,,1", "-1", ",0", "0;1", ""):
+        p = subprocess.run([b, "--devices", bad, "/dev/null"], capture_output=True, stdin=subprocess.DEVNULL, timeout=20)
+        assert p.returncode == 2 and b"--devices takes a comma-separated list" in p.stderr, (bad, p.stderr)
