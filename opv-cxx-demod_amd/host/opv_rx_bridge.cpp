@@ -83,6 +83,10 @@ int main(int argc, char** argv) {
         } else paths.push_back(argv[i]);
     }
     const int S = paths.empty() ? 1 : (int)paths.size();
+    if (base_port < 1 || base_port + S - 1 > 65535) {
+        fprintf(stderr, "opv-rx-bridge: -P %d: ports %d..%d are not valid UDP ports\n", base_port, base_port, base_port + S - 1);
+        return 2;
+    }
     std::vector<Input> in(S);
     for (int k = 0; k < S; ++k) {
         const std::string p = paths.empty() ? "-" : paths[k];
