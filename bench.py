@@ -168,6 +168,9 @@ def main():
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         sys.exit(2)
+    if args.steps < 1 or args.warmup < 0 or args.streams < 1 or args.frames < 1:
+        print("bench.py: --steps, --streams and --frames must be >= 1, --warmup >= 0", file=sys.stderr)
+        sys.exit(2)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus, sys.argv[1:])              # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
