@@ -186,15 +186,31 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal switches for a box with ONE GPU (tests/test_bench_contract.py): OPV_BENCH_SHARE_DEVICE=1 puts every rank
+    # on cuda:0 instead of cuda:LOCAL_RANK, and OPV_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one
+    # device) for the rendezvous, the frame gather and the MAX of the step time. Everything else - rank spawning, the
+    # shard arithmetic, the cross-rank expectation, the N > 1 cpu_baseline leg - is the code the 8-GPU node runs.
+    backend = os.environ.get("OPV_BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        print(f"bench.py: OPV_BENCH_BACKEND={backend!r}: nccl (= RCCL) or gloo", file=sys.stderr)
+        sys.exit(2)
+    dev_index = 0 if os.environ.get("OPV_BENCH_SHARE_DEVICE") == "1" else local_rank
+    if dev_index >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible "
+              f"(one rank per GPU; OPV_BENCH_SHARE_DEVICE=1 + OPV_BENCH_BACKEND=gloo rehearses N > 1 on one)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # OPV_BENCH_FORCE_DIST=1 runs the N>1 code path (RCCL init, gather of the frame buffer, MAX over
     # ranks) even with one rank: a self-test of that path on boxes with a single GPU.
     use_dist = world > 1 or os.environ.get("OPV_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     amd = load_amd()
     amd.lib()
@@ -207,7 +223,7 @@ def main():
     # contiguous shard [r S, (r + 1) S) of the world * S global streams (sharding.stream_range).
     mine = sharding.stream_range(rank, world, world * S)
     n = amd.lib().opv_tx_modulated_samples(F)
-    dm = amd.Demod(S, max_samples=n + 64, streaming=True, device=local_rank)
+    dm = amd.Demod(S, max_samples=n + 64, streaming=True, device=dev_index)
     gen_t = {}
     d_iq, tx_all, n = workload.generate(amd, dm, torch, dev, mine, F, args.ebn0, timing=gen_t)
     t_mod = gen_t["generate_s"]                          # BERT frames + device transmit chain + channel tool, all streams (allocation excluded)
@@ -277,12 +293,16 @@ def main():
     live_clock = float(np.median(cyc / np.maximum(tick, 1.0)) * 100e6) if tick.min() > 0 else None
     collective = None
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # what every rank says it owned: [first global stream, one past the last, samples per stream, frames released]
+        own = torch.tensor([mine.start, mine.stop, n, int(counts_view.sum().item())], dtype=torch.int64, device=t.device)
+        owned = [torch.empty_like(own) for _ in range(world)] if rank == 0 else None
+        dist.gather(own, owned, dst=0)
         if rank == 0:
             g = gathered["frames"]                       # [world, S, fcap, 134] in global stream order
-            assert bool((g[0] == frames_view).all().item()), "gathered frames of rank 0 differ from the local ones"
+            assert bool((g[0].to(dev) == frames_view).all().item()), "gathered frames of rank 0 differ from the local ones"
             stats["gathered_equals_local_view"] = True
             collective = {"backend": dist.get_backend(), "world": world, "gathered_shape": list(g.shape),
                           "bytes_per_rank": int(frames_view.numel() + 4 * counts_view.numel()),
@@ -294,6 +314,12 @@ def main():
             same = (g[:, :, :F, :].cpu().numpy() == exp_all).all(axis=3)
             stats["gathered_frames_total"] = int(same.size)
             stats["gathered_frames_exact"] = int(same.sum())
+            # who sent what, read back from the gathered bytes themselves: the Base-40 callsign of every stream's
+            # first frame is S<global id> (workload.stream_params), so a rank that decoded a second copy of
+            # another rank's shard shows up here (and in exp_all above)
+            collective["rank_shards"] = [[int(o[0]), int(o[1])] for o in owned]
+            collective["rank_frames_released"] = [int(o[3]) for o in owned]
+            collective["gathered_callsigns"] = [amd.callsign_of(g[r, k, 0].cpu().numpy()) for r in range(world) for k in range(S)]
             assert same.mean() > 0.99, "frames gathered from the other ranks do not match what they were sent"
 
     total_samples = float(world) * S * n * args.steps
@@ -388,7 +414,7 @@ def main():
     if rank == 0 and not args.no_extras and world == 1:
         extras = {}
         # configs[1]: one clean 1000-frame stream
-        one = amd.Demod(1, max_samples=n + 64, streaming=True, device=local_rank)
+        one = amd.Demod(1, max_samples=n + 64, streaming=True, device=dev_index)
         d_base = torch.empty(2 * n, dtype=torch.int16, device=dev)
         t0 = time.perf_counter()
         one.modulate_device(tx_frames, d_base.data_ptr())
@@ -416,7 +442,7 @@ def main():
             if S * per < ns:
                 continue
             sub_n = nfr * FRAME_SAMPLES
-            m = amd.Demod(ns, max_samples=sub_n + 64, streaming=True, device=local_rank)
+            m = amd.Demod(ns, max_samples=sub_n + 64, streaming=True, device=dev_index)
             m.enable_timing(True)
             ent = {}
             for spw in (1, 4):                          # streams per wavefront (opv_set_frontend)
@@ -451,7 +477,7 @@ def main():
             sub_n = FH * FRAME_SAMPLES
             host = [d_iq[k][: 2 * sub_n].cpu().pin_memory() for k in range(S)]
             host_np = [h.numpy() for h in host]
-            hp = amd.Demod(S, max_samples=sub_n + 64, streaming=True, device=local_rank)
+            hp = amd.Demod(S, max_samples=sub_n + 64, streaming=True, device=dev_index)
             res = {}
             for mode in ("hbm_attached", "host_pushed", "host_pushed"):
                 hp.reset()
@@ -486,7 +512,7 @@ def main():
             hp.close()
             # live serving round: one 86720-sample chunk (40 ms of signal) per stream pushed from host memory,
             # processed, frames popped - what a multi-stream receiver does every 40 ms
-            lv = amd.Demod(S, max_samples=4 * FRAME_SAMPLES + 65536, streaming=True, device=local_rank)
+            lv = amd.Demod(S, max_samples=4 * FRAME_SAMPLES + 65536, streaming=True, device=dev_index)
             rounds = []
             for r in range(min(14, FH - 1)):
                 blks = [host_np[k][2 * r * FRAME_SAMPLES: 2 * (r + 1) * FRAME_SAMPLES] for k in range(S)]
@@ -516,7 +542,7 @@ def main():
                 if free_b < need_b:
                     extras["configs4_workload_on_one_gpu"] = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, {need_b / 1e9:.0f} GB needed"}
                 else:
-                    big = amd.Demod(512, max_samples=n + 64, streaming=True, device=local_rank)
+                    big = amd.Demod(512, max_samples=n + 64, streaming=True, device=dev_index)
                     d_big, tx_big, _n = workload.generate(amd, big, torch, dev, range(512), F, args.ebn0)
                     big.enable_timing(True)
                     for rep in range(2):

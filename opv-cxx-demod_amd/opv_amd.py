@@ -193,6 +193,18 @@ def bert_frames(n, callsign="W5NYV", token=0xBBAADD, first=0):
     return out
 
 
+def callsign_of(frame):
+    """Base-40 station id of a 134-byte frame's first six bytes (what the reference prints as `Station ID`,
+    ref src/opv-demod.cpp:907-925 / src/opv-mod.cpp:63-90: big-endian 48 bits, first character least significant)"""
+    v = int.from_bytes(bytes(bytearray(frame[:6])), "big")
+    out = ""
+    while v:
+        c = v % 40
+        out += "?" if c == 0 else chr(64 + c) if c <= 26 else chr(48 + c - 27) if c <= 36 else "-/."[c - 37]
+        v //= 40
+    return out
+
+
 def tx_checkpoints(first, count):
     """(ph1, ph2) of the modulator's NCOs at symbols 128 * (first .. first + count - 1) of a run (parity tap)"""
     out = np.empty((count, 2), np.float64)

@@ -34,3 +34,119 @@ def test_recorded_bench_line_has_the_contract_shape():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and 1.0 < c["value"] < 200.0
     assert line["check"]["edge_ties"] == 0 and line["check"]["frames_exact"] >= 0.99 * line["check"]["frames_total"]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bench.py's world > 1 branch, EXECUTED (on the one GPU of the test box): two ranks share cuda:0
+# (OPV_BENCH_SHARE_DEVICE=1) and rendezvous / gather over gloo (OPV_BENCH_BACKEND=gloo; RCCL refuses two ranks on one
+# device). Rank spawning, the per-rank shard, the cross-rank expectation, the MAX of the step time and the N > 1
+# cpu_baseline leg are the lines an 8-GPU node runs; only the transport differs (RCCL's leg: test_gpu_multirank.py).
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+WORLD2_ARGS = ["--gpus", "2", "--streams", "8", "--frames", "12", "--steps", "2", "--warmup", "1"]
+
+
+def _world2_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE",
+                                                            "MASTER_ADDR", "MASTER_PORT", "OPV_BENCH_FORCE_DIST")}
+    env.update(OPV_BENCH_BACKEND="gloo", OPV_BENCH_SHARE_DEVICE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return env
+
+
+def _check_world2_line(p, how):
+    out = ROOT / "gpurun_out"
+    out.mkdir(exist_ok=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    with open(out / "bench_world2.txt", "a") as f:
+        f.write(f"$ OPV_BENCH_BACKEND=gloo OPV_BENCH_SHARE_DEVICE=1 {how}\nexit {p.returncode}\n" + "\n".join(lines) + "\n"
+                + ("--- stderr tail\n" + p.stderr[-3000:] + "\n" if p.returncode else "") + "\n")
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, p.stdout[-2000:]          # ONE line, from rank 0 only
+    line = json.loads(lines[0])
+    S, F = 8, 12
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    c = line["collective"]
+    assert c["backend"] == "gloo" and c["world"] == 2
+    assert c["gathered_shape"][0] == 2 and c["gathered_shape"][1] == S and c["gathered_shape"][3] == 134
+    # rank 1 owns the global streams 8..15 - not a second copy of 0..7: said by the ranks, and read back from the bytes
+    assert c["rank_shards"] == [[0, S], [S, 2 * S]]
+    assert c["gathered_callsigns"] == [f"S{g}" for g in range(2 * S)]
+    assert c["rank_frames_released"] == [S * F, S * F]
+    chk = line["check"]
+    assert chk["gathered_frames_total"] == 2 * S * F
+    assert chk["gathered_frames_exact"] >= 2 * S * F - 2          # 16 dB: at most a stray channel error
+    assert chk["gathered_equals_local_view"] is True and chk["edge_ties"] == 0
+    # whole-job value: the samples of BOTH ranks over the max-over-ranks time
+    n = line["config"]["samples_per_stream"] * S * 2
+    assert abs(line["value"] - n / (line["ms_per_step"] * 1e-3) / 1e6) < 0.01 * line["value"]
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"].startswith("k_msk_frontend") and r["achieved"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 1 and cb["value"] > 0.5
+    return line
+
+
+@pytest.mark.gpu
+def test_bench_world2_started_from_a_bare_shell():
+    """`python bench.py --gpus 2`: spawn_ranks starts both ranks itself and relays rank 0's line"""
+    cmd = [sys.executable, str(ROOT / "bench.py")] + WORLD2_ARGS
+    p = subprocess.run(cmd, env=_world2_env(), capture_output=True, text=True, timeout=420)
+    _check_world2_line(p, "python bench.py " + " ".join(WORLD2_ARGS))
+
+
+@pytest.mark.gpu
+def test_bench_world2_under_the_drivers_launcher():
+    """the driver's own command for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    launch = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", str(port), str(ROOT / "bench.py")] + WORLD2_ARGS
+    p = subprocess.run([sys.executable] + launch, env=_world2_env(), capture_output=True, text=True, timeout=420)
+    _check_world2_line(p, "python " + " ".join(launch[:-len(WORLD2_ARGS) - 1]) + " bench.py " + " ".join(WORLD2_ARGS))
+
+
+@pytest.mark.gpu
+def test_bench_world2_a_dead_rank_takes_the_job_down():
+    """rank 1 is killed while the job runs: the parent ends rank 0 too and exits non-zero within seconds (a surviving
+    rank would otherwise sit in the gather until the rendezvous timeout, half an hour)"""
+    import psutil
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--streams", "8", "--frames", "100", "--steps", "2000", "--warmup", "1"]
+    parent = subprocess.Popen(cmd, env=_world2_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        victim = None
+        t0 = time.time()
+        while victim is None and time.time() - t0 < 120:
+            for ch in psutil.Process(parent.pid).children():
+                try:
+                    if ch.environ().get("RANK") == "1":
+                        victim = ch
+                except psutil.Error:
+                    pass
+            time.sleep(0.1)
+        assert victim is not None, "rank 1 never appeared"
+        time.sleep(20.0)                                   # both ranks are up and inside their steps by now
+        assert parent.poll() is None, parent.communicate()[1][-2000:]
+        victim.kill()
+        t1 = time.time()
+        out, err = parent.communicate(timeout=60)
+        took = time.time() - t1
+    finally:
+        if parent.poll() is None:
+            for ch in psutil.Process(parent.pid).children(recursive=True):
+                ch.kill()
+            parent.kill()
+    assert parent.returncode != 0
+    assert took < 15.0, took
+    assert not [ln for ln in out.splitlines() if ln.startswith('{"metric"')]     # and no bench line from a broken job
+    with open(ROOT / "gpurun_out" / "bench_world2.txt", "a") as f:
+        f.write(f"$ bench.py --gpus 2 ... with rank 1 killed (SIGKILL) 20 s in: parent exit {parent.returncode} after {took:.2f} s, no bench line\n\n")
