@@ -34,6 +34,9 @@ __device__ inline double wave_sum_all(double v) {
     return v;
 }
 __device__ inline double wrap_pi(double p) {  // ref :488-493
+    // (the reference's two loops never end for an infinite phase and take 1e5+ turns per symbol beyond this bound - a `-p` of
+    // 1e9 Hz does that; a wave that never finishes hangs the GPU, so such a phase is folded in one step instead)
+    if (!(fabs(p) < 1.0e6)) return p - kTwoPi * rint(p / kTwoPi);
     while (p > kPi) p -= kTwoPi;
     while (p < -kPi) p += kTwoPi;
     return p;

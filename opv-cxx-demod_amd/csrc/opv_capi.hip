@@ -9,6 +9,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -86,10 +87,13 @@ __global__ void k_apply_inputs(OpvStream* streams, const StreamIn* in, int n) {
     }
 }
 
-__global__ void k_collect_counts(const OpvStream* streams, int32_t* counts, int n) {
+// per round: frames released so far per stream (the zero-copy consumers' counts), and whether ANY stream ended the round
+// held back by back-pressure, OR-ed into a pinned host word (opv_ctx::h_stall) that the next opv_process reads without a copy
+__global__ void k_collect_counts(const OpvStream* streams, int32_t* counts, int n, int* any_stalled) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         counts[i] = (int32_t)streams[i].n_frames;
+        if (streams[i].stalled) *(volatile int*)any_stalled = 1;   // (every writer stores the same 1: no atomic needed across PCIe)
     }
 }
 
@@ -127,6 +131,8 @@ struct opv_ctx {
     static constexpr int kInSlots = 4;
     StreamIn* h_in = nullptr;           // kInSlots x n_streams, pinned
     hipEvent_t in_ev[kInSlots] = {};
+    int* h_stall = nullptr;             // kInSlots words, pinned: round r's "a stream ended stalled" (k_collect_counts), slot r % kInSlots
+    hipEvent_t done_ev = nullptr;       // behind the last round's k_collect_counts
     unsigned round_no = 0;
     std::vector<OpvStream> mirror;  // host copy, refreshed by refresh()
     std::vector<OpvStream> initial; // as created (for reset)
@@ -225,12 +231,41 @@ struct opv_ctx {
     }
 };
 
+// k_tx_modulate.hip decides the flat tops of the transmit NCOs by the symbol index: |sin| / |cos| at a quarter-period point
+// +/- eps is exactly 1.0 while eps < kFlatExact and below 1.0 from kFlatBelow on. True of glibc's correctly rounded-in-practice
+// sin / cos (1 - eps^2/2 rounds to 1.0 while eps^2/2 < 2^-54); a libm with 1 ulp of slack may answer differently, so it is
+// asked, once per process: 5 tops x 2 sides x 2 x 256 offsets.
+constexpr double kFlatExact = 0.90e-8, kFlatBelow = 1.25e-8;
+static bool libm_flat_tops_as_assumed() {
+    static const bool ok = [] {
+        if (std::getenv("OPV_TX_DISTRUST_LIBM")) return false;             // (test hook: forces the every-symbol-from-libm path)
+        const double pi = 3.14159265358979323846;
+        const struct { bool is_sin; double x0; } tops[] = {{true, pi / 2}, {true, -pi / 2}, {false, 0.0}, {false, pi}, {false, -pi}};
+        for (const auto& t : tops)
+            for (int k = 0; k <= 256; ++k) {
+                const double e = kFlatExact * k / 256.0;                                       // must be exactly +/-1
+                const double b = kFlatBelow * std::pow(1.0e-5 / kFlatBelow, k / 256.0);       // must be below: 1.25e-8 .. 1e-5, log-spaced
+                for (double sgn : {1.0, -1.0}) {
+                    const double ve = std::fabs(t.is_sin ? std::sin(t.x0 + sgn * e) : std::cos(t.x0 + sgn * e));
+                    const double vb = std::fabs(t.is_sin ? std::sin(t.x0 + sgn * b) : std::cos(t.x0 + sgn * b));
+                    if (ve != 1.0 || !(vb < 1.0)) return false;
+                }
+            }
+        return true;
+    }();
+    return ok;
+}
+
 extern "C" const char* opv_last_error(void) { return g_err.c_str(); }
 extern "C" int opv_abi_version(void) { return OPV_ABI_VERSION; }
 
 extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
     if (!out || !cfg || n_streams <= 0 || cfg->max_samples == 0) return fail(OPV_EINVAL, "opv_create: bad arguments");
     if (cfg->max_samples >= (1ull << 31)) return fail(OPV_EINVAL, "opv_create: max_samples must be < 2^31");
+    // the reference's phase wraps are `while (ph > pi) ph -= 2 pi` loops (src/opv-demod.cpp:255-262,488-493): with an infinite -o / -a / -p
+    // it spins forever on its CPU; here that would be a wave that never finishes, so such values are refused up front
+    if ((cfg->have_init_offset && !std::isfinite(cfg->init_offset_hz)) || !std::isfinite(cfg->afc_alpha) || (cfg->coherent && !std::isfinite(cfg->pll_bw_hz)))
+        return fail(OPV_EINVAL, "opv_create: init_offset_hz / afc_alpha / pll_bw_hz must be finite");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(OPV_ENODEV, "no HIP device visible");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(OPV_ENODEV, "opv_cfg.device out of range");
@@ -266,6 +301,9 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
     const size_t S = (size_t)n_streams;
     HIPCHK_C(hipHostMalloc(&c->h_in, sizeof(StreamIn) * S * opv_ctx::kInSlots, hipHostMallocDefault));
     for (auto& e : c->in_ev) HIPCHK_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK_C(hipHostMalloc(&c->h_stall, sizeof(int) * opv_ctx::kInSlots, hipHostMallocDefault));
+    for (int i = 0; i < opv_ctx::kInSlots; ++i) c->h_stall[i] = 0;
+    HIPCHK_C(hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming));
     HIPCHK_C(hipMalloc(&c->d_streams, sizeof(OpvStream) * S));
     HIPCHK_C(hipMalloc(&c->d_in, sizeof(StreamIn) * S));
     HIPCHK_C(hipMalloc(&c->d_soft, sizeof(double) * c->cap_soft * S));
@@ -333,6 +371,8 @@ extern "C" void opv_destroy(opv_ctx* c) {
     for (auto& e : c->in_ev)
         if (e) (void)hipEventDestroy(e);
     if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_stall) (void)hipHostFree(c->h_stall);
+    if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& h : c->hs) {
         if (h.d_iq_owned) (void)hipFree(h.d_iq_owned);
@@ -472,10 +512,15 @@ extern "C" int opv_process(opv_ctx* c) {
         h.dirty = false;
     }
     // nothing new: still run the round while a stream may be waiting behind back-pressure (it resumes by itself once
-    // the tracker has consumed soft symbols / the caller has popped frames; the cursors travel with every round)
+    // the tracker has consumed soft symbols / the caller has popped frames; the cursors travel with every round).
+    // Whether one is: the last round's kernels said so in a pinned word (a caller on the zero-copy path - opv_device_frames +
+    // opv_sync, no pops - never refreshes the mirror); while that round is still running the answer is "maybe".
+    if (!any && c->maybe_stalled && c->round_no > 0 && hipEventQuery(c->done_ev) == hipSuccess)
+        c->maybe_stalled = c->h_stall[(c->round_no - 1) % opv_ctx::kInSlots] != 0;
     if (!any && !c->maybe_stalled) return OPV_OK;
     c->mirror_valid = false;
     c->maybe_stalled = true;
+    c->h_stall[slot] = 0;          // (a straggler of round_no - kInSlots could still set it: then one idle round too many, never one too few)
     // pinned -> device, in stream order behind the previous round's kernels; no host wait
     HIPCHK(hipMemcpyAsync(c->d_in, in, sizeof(StreamIn) * S, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->in_ev[slot], c->stream));
@@ -527,7 +572,8 @@ extern "C" int opv_process(opv_ctx* c) {
     k_frame_scale<<<(unsigned)((fr * (uint64_t)S + 63) / 64), 64, 0, c->stream>>>(c->d_streams, (uint32_t)fr, (uint32_t)S);
     k_frame_decode<<<(unsigned)(fr * (uint64_t)S), 64, 0, c->stream>>>(c->d_streams, (uint32_t)fr);
     if (tm) { HIPCHK(hipEventRecord(c->ev[7], c->stream)); c->timing_valid = true; }
-    k_collect_counts<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_counts, S);
+    k_collect_counts<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_counts, S, c->h_stall + slot);
+    HIPCHK(hipEventRecord(c->done_ev, c->stream));
     HIPCHK(hipGetLastError());
     return OPV_OK;
 }
@@ -891,7 +937,11 @@ extern "C" long opv_tx_modulate_device(opv_ctx* c, const uint8_t* frames, size_t
         HIPCHK(hipGetLastError());
         c->tx_phases_have = nsym;
     }
-    // ---- flat tops: the zone limits from the checkpoint sequence (the drift is monotone), the bits in between from libm
+    // ---- flat tops: the zone limits from the checkpoint sequence (the drift is monotone), the bits in between from libm.
+    // Both zone limits are statements about THIS process's libm (glibc: exactly 1.0 while eps < 1.05e-8); they are probed once
+    // per process (libm_flat_tops_as_assumed), and the partition the binary search relies on is spot-checked. If either fails -
+    // another libm, a drift that is not monotone - every symbol's bits come from libm (flat_lo = 0, no upper zone): slower to
+    // set up (two sincos per symbol of the run on the host), identical to `opv-mod` on this machine by construction.
     if (c->tx_flat_hi == ~0ull) {                            // (both limits found: final - the sequence is data-independent)
         const size_t n_ck = (nsym + OPV_TX_CKPT_SYMS - 1) / OPV_TX_CKPT_SYMS;
         auto drift = [](size_t j) {                          // distance of checkpoint j's phases from a multiple of pi/2
@@ -906,9 +956,20 @@ extern "C" long opv_tx_modulate_device(opv_ctx* c, const uint8_t* frames, size_t
             while (lo < hi) { const size_t mid = lo + (hi - lo) / 2; if (drift(mid) >= thr) hi = mid; else lo = mid + 1; }
             return lo;
         };
-        const size_t j_lo = n_ck ? first_at(0.90e-8) : 0, j_hi = n_ck ? first_at(1.25e-8) : 0;
-        c->tx_flat_lo = j_lo >= n_ck ? ~0ull : (uint64_t)(j_lo ? j_lo - 1 : 0) * OPV_TX_CKPT_SYMS;
-        c->tx_flat_hi = j_hi >= n_ck ? ~0ull : (uint64_t)(j_hi + 1) * OPV_TX_CKPT_SYMS;
+        const size_t j_lo = n_ck ? first_at(kFlatExact) : 0, j_hi = n_ck ? first_at(kFlatBelow) : 0;
+        bool ok = libm_flat_tops_as_assumed();
+        for (size_t t = 0; ok && n_ck && t < 16; ++t) {     // the partition the search assumed, at 16 places across the run
+            const size_t j = t * (n_ck - 1) / 15;
+            const double d = drift(j);
+            ok = (d >= kFlatExact) == (j >= j_lo) && (d >= kFlatBelow) == (j >= j_hi);
+        }
+        if (ok) {
+            c->tx_flat_lo = j_lo >= n_ck ? ~0ull : (uint64_t)(j_lo ? j_lo - 1 : 0) * OPV_TX_CKPT_SYMS;
+            c->tx_flat_hi = j_hi >= n_ck ? ~0ull : (uint64_t)(j_hi + 1) * OPV_TX_CKPT_SYMS;
+        } else {
+            c->tx_flat_lo = 0;
+            c->tx_flat_hi = ~0ull - 1;                       // (not the "unknown" value: final)
+        }
     }
     if (c->tx_flat_lo != ~0ull && nsym > c->tx_flat_lo) {
         const uint64_t want = c->tx_flat_hi < (uint64_t)nsym ? c->tx_flat_hi : (uint64_t)nsym;   // bits for [flat_lo, want)

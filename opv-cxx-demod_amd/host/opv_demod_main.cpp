@@ -46,14 +46,14 @@ const char* state_name(int s) {  // ref :75-82
     return s == OPV_HUNTING ? "HUNTING" : s == OPV_VERIFYING ? "VERIFYING" : s == OPV_LOCKED ? "LOCKED" : "?";
 }
 
-void print_event(const opv_event& e) {  // ref :651,677,695,699,705
+void print_event(FILE* err, const opv_event& e) {  // ref :651,677,695,699,705
     const unsigned long long i = e.sym_idx;
     switch (e.kind) {
-        case OPV_EV_HUNT_TO_VERIFY: fprintf(stderr, "[%llu] HUNTING→VERIFYING (corr=%.3f, raw=%.0f)\n", i, e.corr, e.raw); break;
-        case OPV_EV_VERIFY_TO_LOCK: fprintf(stderr, "[%llu] VERIFYING→LOCKED (frame %d)\n", i, e.count); break;
-        case OPV_EV_SYNC_OK: fprintf(stderr, "[%llu] LOCKED: sync OK (corr=%.3f)\n", i, e.corr); break;
-        case OPV_EV_SYNC_MISS: fprintf(stderr, "[%llu] LOCKED: sync MISS #%d (corr=%.3f)\n", i, e.count, e.corr); break;
-        case OPV_EV_LOST_LOCK: fprintf(stderr, "[%llu] LOCKED→HUNTING (lost lock)\n", i); break;
+        case OPV_EV_HUNT_TO_VERIFY: fprintf(err, "[%llu] HUNTING→VERIFYING (corr=%.3f, raw=%.0f)\n", i, e.corr, e.raw); break;
+        case OPV_EV_VERIFY_TO_LOCK: fprintf(err, "[%llu] VERIFYING→LOCKED (frame %d)\n", i, e.count); break;
+        case OPV_EV_SYNC_OK: fprintf(err, "[%llu] LOCKED: sync OK (corr=%.3f)\n", i, e.corr); break;
+        case OPV_EV_SYNC_MISS: fprintf(err, "[%llu] LOCKED: sync MISS #%d (corr=%.3f)\n", i, e.count, e.corr); break;
+        case OPV_EV_LOST_LOCK: fprintf(err, "[%llu] LOCKED→HUNTING (lost lock)\n", i); break;
         default: break;
     }
 }
@@ -93,7 +93,7 @@ void dump_row(Text& t, const uint8_t* f, size_t at) {
 }
 }  // namespace box
 
-void print_frame(int num, const uint8_t* f, int metric, double sync) {
+void print_frame(FILE* err, int num, const uint8_t* f, int metric, double sync) {
     box::Text t;
     t.s.reserve(2048);
     t.s += box::kTop;
@@ -107,7 +107,7 @@ void print_frame(int num, const uint8_t* f, int metric, double sync) {
     t.s += "│ Hex Dump:                                                       │\n";
     for (size_t at = 0; at < OPV_FRAME_BYTES; at += 16) box::dump_row(t, f, at);
     t.s += box::kBot;
-    fwrite(t.s.data(), 1, t.s.size(), stderr);
+    fwrite(t.s.data(), 1, t.s.size(), err);
 }
 
 struct Options {
@@ -124,6 +124,7 @@ struct Sink {
     uint64_t total_samples = 0, total_symbols = 0;
     uint64_t full_samples = 0, full_symbols = 0;  // what the reference's Total: line counts (full chunks only, ref :1027,:1067)
     bool est_printed = false;
+    FILE* err = stderr;  // where tracker lines and frame boxes go (batch mode holds them back while a stalled stream finishes)
 
     void write_frame(const uint8_t* f) {
         // one write(2) per frame, like the 134-byte fully-buffered stdout of the reference (ref :978-979)
@@ -176,13 +177,13 @@ struct Sink {
                 const bool hf = ifr < all_meta.size() && all_meta[ifr].release_symbol < sym_end;
                 if (!he && !hf) break;
                 if (he && (!hf || all_ev[ie].sym_idx <= all_meta[ifr].release_symbol)) {
-                    print_event(all_ev[ie++]);  // tracker lines are printed even under -q (ref :651)
+                    print_event(err, all_ev[ie++]);  // tracker lines are printed even under -q (ref :651)
                 } else {
                     const opv_frame_meta& m = all_meta[ifr];
                     const uint8_t* f = all_fr.data() + ifr * OPV_FRAME_BYTES;
                     ++decoded;
                     if (m.viterbi_metric == 0) ++perfect;
-                    if (!o.quiet) print_frame(decoded, f, m.viterbi_metric, m.sync_quality);
+                    if (!o.quiet) print_frame(err, decoded, f, m.viterbi_metric, m.sync_quality);
                     if (o.raw) write_frame(f);
                     ++ifr;
                 }
@@ -369,12 +370,28 @@ int main(int argc, char** argv) {
     if (opv_flush(ctx, 0) < 0 || opv_process(ctx) < 0) return die("opv_process");
     opv_stream_state st;
     if (opv_get_state(ctx, 0, &st) < 0) return die("opv_get_state");
+    Sink sink{ctx, o};
+    // The reference prints its symbol count and final AFC value BEFORE the frames (:1170-1175). The device rings are sized for
+    // the whole capture (max_samples = n + 64), so the one opv_process above has normally finished the stream; should
+    // back-pressure have held it back all the same, the stream is finished first - tracker lines and frame boxes collected
+    // in memory - so that the line reports the final figures, then they follow it.
+    char* held = nullptr;
+    size_t held_n = 0;
+    if (st.stalled) {
+        sink.err = open_memstream(&held, &held_n);
+        if (!sink.err) return die("open_memstream");
+        if (sink.drain() < 0) return die("drain");
+        if (finish(ctx, sink) < 0) return die("finish");
+        fclose(sink.err);
+        sink.err = stderr;
+        if (opv_get_state(ctx, 0, &st) < 0) return die("opv_get_state");
+    }
     if (!o.quiet) {
         fprintf(stderr, "Estimated carrier offset: %.1f Hz\n", st.est_offset_hz);  // ref :1151 / :1170
         if (o.coherent) fprintf(stderr, "PLL bandwidth: %.1f Hz\n", o.pll_bw);       // ref :1157
         fprintf(stderr, "Demodulated %llu symbols, final AFC offset: %.1f Hz\n\n", (unsigned long long)st.total_symbols, st.freq_offset_hz);
     }
-    Sink sink{ctx, o};
+    if (held) { fwrite(held, 1, held_n, stderr); free(held); }
     if (sink.drain() < 0) return die("drain");
     if (finish(ctx, sink) < 0) return die("finish");
     if (opv_get_state(ctx, 0, &st) < 0) return die("opv_get_state");

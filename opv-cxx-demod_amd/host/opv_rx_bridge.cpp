@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
             for (const char* p = argv[++i]; *p;) {
                 char* end = nullptr;
                 const long v = strtol(p, &end, 10);
-                if (end == p || v < 0 || v > 1023 || (*end != ',' && *end != 0)) {     // ("x,y", "0,,1", "-1": not a list of ordinals)
+                if (end == p || v < 0 || v > 1023 || (*end != ',' && *end != 0) || (*end == ',' && end[1] == 0)) {     // ("x,y", "0,,1", "0,1,", "-1": not a list of ordinals)
                     fprintf(stderr, "opv-rx-bridge: --devices takes a comma-separated list of HIP device ordinals, got '%s'\n", argv[i]);
                     return 2;
                 }

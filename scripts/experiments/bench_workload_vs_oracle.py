@@ -1,7 +1,7 @@
 """one-off soak: EVERY stream of bench.py's workload (64 streams x 1000 frames, 16 dB, f0 -1500..+1500 Hz: BASELINE configs[3])
 through the HIP path in one context, and through the CPU oracle (8 worker processes, one stream at a time in host memory):
 frames, Viterbi metrics, sync positions, tracker events (kind / count / symbol), symbol count, offset estimate of every stream.
-tests/test_gpu_parity.py::test_config3_full_size_sampled_streams does four of the 64 in every suite run."""
+tests/test_gpu_parity.py::test_config3_full_size_all_streams does the same in every suite run (round 4); this prints a line per stream."""
 import sys
 import time
 from concurrent.futures import ProcessPoolExecutor
@@ -14,10 +14,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
-def oracle_job(x):
-    from oracle_lib import Oracle
-    e = Oracle().receive(x, streaming=True, want_soft=False)
-    return {k: e[k] for k in ("frames", "metrics", "frame_sym", "events", "n_soft", "est_offset", "final_freq_offset")}
+from soak_inputs import oracle_receive_job as oracle_job  # noqa: E402  (shared with tests/test_gpu_parity.py)
 
 
 def main():

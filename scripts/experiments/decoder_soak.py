@@ -14,36 +14,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 
 
-def make(n, seed):
-    from oracle_lib import Oracle
-    o = Oracle()
-    rng = np.random.default_rng(seed)
-    soft = np.empty((n, 2144))
-    for k in range(n):
-        kind = k % 8
-        if kind in (0, 1, 2):            # a real coded frame: bit 1 -> negative soft, plus noise of three strengths
-            bits = o.encode_frame(rng.integers(0, 256, 134, dtype=np.uint8)).astype(np.float64)
-            s = (1.0 - 2.0 * bits) * 2.4e11
-            soft[k] = s + rng.standard_normal(2144) * 2.4e11 * (0.3, 0.8, 1.6)[kind]
-        elif kind == 3:
-            soft[k] = rng.standard_normal(2144) * 3e10
-        elif kind == 4:                  # few levels: exact ties in the trellis and on quantiser boundaries
-            soft[k] = rng.integers(-3, 4, 2144) * 1e10
-        elif kind == 5:
-            soft[k] = rng.standard_normal(2144) * 10.0 ** rng.uniform(-12, 3)      # around the 1e-10 drop threshold
-        elif kind == 6:
-            soft[k] = rng.standard_normal(2144) * 1e200
-        else:
-            s = rng.standard_normal(2144) * 1e11
-            s[rng.random(2144) < rng.uniform(0.1, 0.99)] = 0.0
-            soft[k] = s
-    return soft
-
-
-def oracle_chunk(soft):
-    from oracle_lib import Oracle
-    o = Oracle()
-    return [o.frame_decode(s) for s in soft]
+from soak_inputs import decoder_payloads as make, oracle_decode_chunk as oracle_chunk  # noqa: E402  (shared with tests/test_gpu_parity.py)
 
 
 def main():

@@ -16,37 +16,11 @@ SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 S = 512
 
 
+from soak_inputs import offset_openings, oracle_offset_chunk as oracle_chunk  # noqa: E402  (shared with tests/test_gpu_parity.py)
+
+
 def make(seed):
-    from oracle_lib import Oracle, impair
-    o = Oracle()
-    rng = np.random.default_rng(seed)
-    base = o.modulate(o.bert_frames(3, "K%d" % (seed % 1000), first=seed))
-    caps = []
-    for k in range(S):
-        n = int(rng.choice([3000, 8000, 20000, 39999, 40000, 40001, 45000]))
-        at = int(rng.integers(0, base.size // 2 - n - 1))
-        x = base[2 * at: 2 * (at + n)]
-        kind = k % 10
-        if kind == 8:                                            # noise only
-            x = np.zeros_like(x)
-            x = impair(x + 1, amp=float(rng.uniform(50, 3000)), ebn0_db=-20.0, seed=seed * 1000 + k)
-        elif kind == 9:                                          # digital silence with a burst somewhere
-            y = np.zeros_like(x)
-            a, b = sorted(int(v) for v in rng.integers(0, n, 2))
-            y[2 * a: 2 * b] = x[2 * a: 2 * b]
-            x = y
-        else:
-            ebn0 = None if kind == 0 else float(rng.uniform(0, 25))
-            x = impair(x, amp=float(rng.uniform(100, 16000)), f0_hz=float(rng.uniform(-2500, 2500)), ebn0_db=ebn0,
-                       seed=seed * 1000 + k)
-        caps.append(np.ascontiguousarray(x))
-    return caps
-
-
-def oracle_chunk(caps):
-    from oracle_lib import Oracle
-    o = Oracle()
-    return [o.estimate_offset(c) for c in caps]
+    return offset_openings(seed, S)
 
 
 def main():

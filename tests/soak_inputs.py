@@ -1,0 +1,88 @@
+"""Seeded input generators shared by the soak scripts (scripts/experiments/decoder_soak.py, offset_soak.py: tens of
+thousands of cases, run by hand) and by the slices of them that run in every `pytest -m gpu` (tests/test_gpu_parity.py).
+Test infrastructure: the inputs come from the CPU oracle's transmit chain and the numpy channel model."""
+import numpy as np
+
+
+def decoder_payloads(n, seed):
+    """n x 2144 soft-symbol payloads for FrameDecoder::decode (ref src/opv-demod.cpp:854-898) of eight kinds: real coded
+    frames at three noise levels, pure noise, few-level inputs full of trellis ties and quantiser boundaries, scales around
+    the 1e-10 drop threshold, huge scales, sparse zeros."""
+    from oracle_lib import Oracle
+    o = Oracle()
+    rng = np.random.default_rng(seed)
+    soft = np.empty((n, 2144))
+    for k in range(n):
+        kind = k % 8
+        if kind in (0, 1, 2):            # a real coded frame: bit 1 -> negative soft, plus noise of three strengths
+            bits = o.encode_frame(rng.integers(0, 256, 134, dtype=np.uint8)).astype(np.float64)
+            s = (1.0 - 2.0 * bits) * 2.4e11
+            soft[k] = s + rng.standard_normal(2144) * 2.4e11 * (0.3, 0.8, 1.6)[kind]
+        elif kind == 3:
+            soft[k] = rng.standard_normal(2144) * 3e10
+        elif kind == 4:                  # few levels: exact ties in the trellis and on quantiser boundaries
+            soft[k] = rng.integers(-3, 4, 2144) * 1e10
+        elif kind == 5:
+            soft[k] = rng.standard_normal(2144) * 10.0 ** rng.uniform(-12, 3)      # around the 1e-10 drop threshold
+        elif kind == 6:
+            soft[k] = rng.standard_normal(2144) * 1e200
+        else:
+            s = rng.standard_normal(2144) * 1e11
+            s[rng.random(2144) < rng.uniform(0.1, 0.99)] = 0.0
+            soft[k] = s
+    return soft
+
+
+def oracle_decode_chunk(soft):
+    from oracle_lib import Oracle
+    o = Oracle()
+    return [o.frame_decode(s) for s in soft]
+
+
+def offset_openings(seed, n_streams=512):
+    """n_streams random openings of a capture for estimate_offset (ref src/opv-demod.cpp:131-202): random start inside a BERT
+    run, carrier offset in and beyond the +/-1530 Hz span, level, Eb/N0 from 0 dB to clean, lengths from 3000 to 45000 samples
+    (the search uses min(N, 40000)), some pure noise and some digital silence with a burst."""
+    from oracle_lib import Oracle, impair
+    o = Oracle()
+    rng = np.random.default_rng(seed)
+    base = o.modulate(o.bert_frames(3, "K%d" % (seed % 1000), first=seed))
+    caps = []
+    for k in range(n_streams):
+        n = int(rng.choice([3000, 8000, 20000, 39999, 40000, 40001, 45000]))
+        at = int(rng.integers(0, base.size // 2 - n - 1))
+        x = base[2 * at: 2 * (at + n)]
+        kind = k % 10
+        if kind == 8:                                            # noise only
+            x = np.zeros_like(x)
+            x = impair(x + 1, amp=float(rng.uniform(50, 3000)), ebn0_db=-20.0, seed=seed * 1000 + k)
+        elif kind == 9:                                          # digital silence with a burst somewhere
+            y = np.zeros_like(x)
+            a, b = sorted(int(v) for v in rng.integers(0, n, 2))
+            y[2 * a: 2 * b] = x[2 * a: 2 * b]
+            x = y
+        else:
+            ebn0 = None if kind == 0 else float(rng.uniform(0, 25))
+            x = impair(x, amp=float(rng.uniform(100, 16000)), f0_hz=float(rng.uniform(-2500, 2500)), ebn0_db=ebn0,
+                       seed=seed * 1000 + k)
+        caps.append(np.ascontiguousarray(x))
+    return caps
+
+
+def oracle_offset_chunk(caps):
+    from oracle_lib import Oracle
+    o = Oracle()
+    return [o.estimate_offset(c) for c in caps]
+
+
+def oracle_receive_job(x):
+    """one stream through the oracle's whole receive chain (-s semantics), without the soft log"""
+    from oracle_lib import Oracle
+    e = Oracle().receive(x, streaming=True, want_soft=False)
+    return {k: e[k] for k in ("frames", "metrics", "frame_sym", "events", "n_soft", "est_offset", "final_freq_offset")}
+
+
+def host_workers(cap=16):
+    """worker processes for the oracle side: the cores this job may use (a one-GPU box of the pool gives 16)"""
+    import os
+    return max(1, min(len(os.sched_getaffinity(0)), cap))

@@ -18,6 +18,14 @@ sys.path.insert(0, str(ROOT / "tests"))
 pytestmark = pytest.mark.gpu
 
 
+def _free_port():
+    """an OS-assigned free TCP port for a rendezvous on 127.0.0.1 (as conftest.run_rccl_selftest picks its own)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _rank_main(rank, world, port, per_rank, n_frames, ebn0, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -81,7 +89,7 @@ def test_world2_real_pipeline_every_global_stream_vs_oracle():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 400)
+    port = _free_port()
     procs = [ctx.Process(target=_rank_main, args=(r, 2, port, 8, 12, 16.0, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -168,7 +176,7 @@ def test_gather_frames_under_nccl_world_1():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_nccl_world1_main, args=(29900 + (os.getpid() % 90), q))
+    p = ctx.Process(target=_nccl_world1_main, args=(_free_port(), q))
     p.start()
     p.join(600)
     assert p.exitcode == 0

@@ -1,0 +1,237 @@
+"""CPU sanitizer job (the reference builds with none, reference Makefile:2): the product's HOST code - host/opv_demod_main.cpp,
+host/opv_mod_main.cpp, host/opv_rx_bridge.cpp, csrc/opv_tx.cpp (worker threads) - and oracle/opv_oracle.c, built by `make -C opv-cxx-demod_amd san`
+with g++ -fsanitize=address,undefined -fno-sanitize-recover=all and a second time with -fsanitize=thread, against tests/san/fake_device.cpp (the CPU
+oracle behind the C ABI's device entry points; GPU AddressSanitizer is not available on the pool). What runs here is what faces the outside: argv,
+pipes written in ragged pieces, UDP datagrams of any size, sources that end in the middle of a sample. A sanitizer report fails the test (exit code
+99 + its text on stderr); beyond that the outputs are compared with the reference binary / the reference-made fixtures."""
+import hashlib
+import os
+import socket
+import subprocess
+import threading
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+PKG = ROOT / "opv-cxx-demod_amd"
+REF_DEMOD = ROOT / "oracle" / "_ref" / "opv-demod"
+SAN_ENV = dict(os.environ, ASAN_OPTIONS="exitcode=99:detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="exitcode=99:halt_on_error=1:print_stacktrace=1",
+               TSAN_OPTIONS="exitcode=99:halt_on_error=1")
+
+
+@pytest.fixture(scope="module")
+def san():
+    p = subprocess.run(["make", "-C", str(PKG), "-j8", "san"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    return {v: {n: str(PKG / "build" / "san" / v / n) for n in ("opv-demod", "opv-mod", "opv-rx-bridge")} for v in ("asan", "tsan")}
+
+
+def run(cmd, data=b"", timeout=300, env=None):
+    p = subprocess.run(cmd, input=data, capture_output=True, timeout=timeout, env=env or SAN_ENV)
+    err = p.stderr.decode(errors="replace")
+    assert p.returncode != 99 and "Sanitizer" not in err and "runtime error" not in err, f"{' '.join(cmd)}\n{err[-4000:]}"
+    return p
+
+
+def feed_ragged(cmd, data, sizes, timeout=300):
+    """the input written in pieces of the given sizes (cycled), with a flush after each: short reads, samples split across reads"""
+    p = subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=SAN_ENV)
+    out = {}
+
+    def rd(name, f):
+        out[name] = f.read()
+    th = [threading.Thread(target=rd, args=("o", p.stdout)), threading.Thread(target=rd, args=("e", p.stderr))]
+    for t in th:
+        t.start()
+    at = k = 0
+    while at < len(data):
+        n = sizes[k % len(sizes)]
+        p.stdin.write(data[at:at + n])
+        p.stdin.flush()
+        at += n
+        k += 1
+    p.stdin.close()
+    rc = p.wait(timeout=timeout)
+    for t in th:
+        t.join()
+    err = out["e"].decode(errors="replace")
+    assert rc != 99 and "Sanitizer" not in err and "runtime error" not in err, err[-4000:]
+    return rc, out["o"], out["e"]
+
+
+@pytest.mark.parametrize("variant", ["asan", "tsan"])
+def test_opv_mod_and_opv_demod_loopback_under_sanitizers(san, golden, variant):
+    """BASELINE configs[0] through the sanitized host programs: `opv-mod -S W5NYV -B 10` (frame-parallel worker threads: the TSan build is
+    about these) gives the reference's IQ bytes (sha256 pin), `opv-demod -s -r` and `opv-demod -r` fed in ragged pieces give
+    the reference's stdout and stderr (reference-made fixtures), -R with frames arriving in split writes equals -B."""
+    arrays, meta = golden
+    b = san[variant]
+    iq = run([b["opv-mod"], "-S", "W5NYV", "-B", "10"]).stdout
+    assert hashlib.sha256(iq).hexdigest() == "d525981a3ad372724db45ab9882896d46b2b79f3214bcf8a07ddd82845b4b317"
+    for flags, text, sizes in ((["-s", "-r"], "c1_stream_stderr.txt", [4096, 3, 1, 65536, 7, 250001]), (["-r"], "c1_batch_stderr.txt", [99999, 2, 5])):
+        rc, out, err = feed_ragged([b["opv-demod"]] + flags, iq, sizes)
+        assert rc == 0 and hashlib.sha256(out).hexdigest() == "948f66c3ab475fe492b2b9a0dc0ab2e5ed7c0f9508ac8bd01dc2696a4849c18e"
+        assert err.decode() == (ROOT / "tests" / "golden" / text).read_text()
+    # a stream that ends its first round held back by back-pressure (the fake's OPV_FAKE_STALL): both modes finish it and print
+    # the reference's text all the same - batch mode's "Demodulated N symbols, final AFC offset" line with the FINAL figures
+    for flags, text in ((["-s", "-r"], "c1_stream_stderr.txt"), (["-r"], "c1_batch_stderr.txt")):
+        p = run([b["opv-demod"]] + flags, iq, env=dict(SAN_ENV, OPV_FAKE_STALL="1"))
+        assert p.returncode == 0 and hashlib.sha256(p.stdout).hexdigest() == "948f66c3ab475fe492b2b9a0dc0ab2e5ed7c0f9508ac8bd01dc2696a4849c18e"
+        assert p.stderr.decode() == (ROOT / "tests" / "golden" / text).read_text(), flags
+    # raw mode: the ten BERT frames cut out of the decoded stream go back in, in writes that split frames
+    frames = np.frombuffer(out, np.uint8).reshape(-1, 134)
+    rc, iq_r, err = feed_ragged([b["opv-mod"], "-R", "-v"], frames.tobytes(), [1, 133, 134, 200, 67])
+    assert rc == 0 and iq_r == iq
+    # a partial last frame is reported and dropped like the reference does (src/opv-mod.cpp:365-387)
+    rc, iq_p, err = feed_ragged([b["opv-mod"], "-R"], frames[:2].tobytes() + b"\x00" * 57, [300])
+    assert rc == 0 and b"partial frame (57 bytes)" in err and len(iq_p) == 4 * (2 * 86720 + 4000)
+
+
+def test_opv_mod_flag_errors_and_many_frames_under_tsan(san):
+    b = san["tsan"]
+    iq = run([b["opv-mod"], "-S", "KB5MU", "-B", "150", "-t", "0x123456"]).stdout          # three blocks of 64 frames on every worker thread
+    assert len(iq) == 4 * (150 * 86720 + 4000)
+    a = san["asan"]
+    for args in ([], ["-B", "3"], ["-R", "-B", "2", "-S", "X"], ["-S", "ABCDEFGHIJKL", "-B", "0"], ["-x"], ["-G", "0", "-c", "-S", "A", "-B", "1"]):
+        assert run([a["opv-mod"]] + args).returncode == 1
+    p = run([a["opv-mod"], "-S", "ABCDEFGHIJKL", "-B", "1", "-v", "-G", "0"])             # -G: the fake's device chain is the host modulator
+    assert p.returncode == 0 and b"truncated to 9" in p.stderr and len(p.stdout) == 4 * (86720 + 4000)
+
+
+@pytest.mark.skipif(not REF_DEMOD.exists(), reason="oracle/_ref/opv-demod not built (no /root/reference here)")
+def test_opv_demod_degenerate_inputs_equal_the_reference_binary(san):
+    """scripts/experiments/cli_degenerate.py's 102 runs (empty, a few bytes, less than a symbol / a chunk, odd byte counts, noise, zeros; six flag
+    sets) on the ASan+UBSan opv-demod: exit status, stdout and stderr equal the reference binary's, and no sanitizer report"""
+    b = san["asan"]
+    sig = run([b["opv-mod"], "-S", "W5NYV", "-B", "2"]).stdout
+    rng = np.random.default_rng(1)
+    inputs = {"empty": b"", "1 byte": b"\x01", "3 bytes": b"\x01\x02\x03", "1 sample": b"\x10\x00\x20\x00", "39 samples": sig[:39 * 4],
+              "40 samples": sig[:160], "49 samples": sig[:49 * 4], "50 samples": sig[:200], "51 samples + 1 byte": sig[:205],
+              "1000 samples": sig[:4000], "40000 samples": sig[:160000], "40001 samples": sig[:160004], "one chunk - 1": sig[: 86719 * 4],
+              "one chunk": sig[: 86720 * 4], "one chunk + 3 bytes": sig[: 86720 * 4 + 3],
+              "noise 5000": rng.integers(-3000, 3000, 10000).astype(np.int16).tobytes(), "zeros 100000": bytes(400000)}
+    n = 0
+    for name, data in inputs.items():
+        for flags in (["-s"], ["-s", "-r", "-q"], [], ["-r"], ["-q", "-o", "300"], ["-s", "-o", "-250", "-a", "0.002"]):
+            ours = run([b["opv-demod"]] + flags, data)
+            ref = subprocess.run([str(REF_DEMOD)] + flags, input=data, capture_output=True, timeout=120)
+            assert (ours.returncode, ours.stdout) == (ref.returncode, ref.stdout), (name, flags)
+            assert ours.stderr == ref.stderr, (name, flags)
+            n += 1
+    assert n == 102
+    # flags at the end of argv without their value, unknown flags, -h: handled like the reference's hand-rolled loop (src/opv-demod.cpp:950-974)
+    for flags in (["-a"], ["-o"], ["-p"], ["--device"], ["-zzz", "-s", "-q"], ["-s", "-a", "nonsense", "-o", "99999", "-q"]):
+        ours = run([b["opv-demod"]] + flags, sig[:200000])
+        ref = subprocess.run([str(REF_DEMOD)] + flags, input=sig[:200000], capture_output=True, timeout=120)
+        assert (ours.returncode, ours.stdout, ours.stderr) == (ref.returncode, ref.stdout, ref.stderr), flags
+    assert run([b["opv-demod"], "-h"]).returncode == 0
+    p = run([b["opv-demod"], "-s"], b"\x00" * 4000, env=dict(SAN_ENV, OPV_FAKE_NODEV="1"))      # no device: loud, exit 2, nothing leaked
+    assert p.returncode == 2 and b"opv_create" in p.stderr
+
+
+def _udp_listeners(n):
+    for base in range(42000 + os.getpid() % 2000, 60000, 53):
+        socks = []
+        try:
+            for k in range(n):
+                s = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+                s.bind(("127.0.0.1", base + k))
+                s.setblocking(False)
+                socks.append(s)
+            return base, socks
+        except OSError:
+            for s in socks:
+                s.close()
+    raise RuntimeError("no free port range")
+
+
+def _free_udp_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_DGRAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("variant", ["asan", "tsan"])
+def test_rx_bridge_hostile_sources_under_sanitizers(san, oracle, iq10, tmp_path, variant):
+    """opv-rx-bridge turns bytes from outside into opv_push_iq calls. Four streams at once: stdin written in ragged pieces and closed in the MIDDLE of
+    a sample; a file with three stray bytes at its end; a UDP source sending datagrams of 1, 2, 3, 5, 1001 and 65507 bytes (samples straddle
+    datagrams) and a zero-length one to finish; a UDP source that sends nothing but the zero-length datagram. Sharded over two 'devices' with the
+    C++ gather at the end. Every stream's datagrams out are the oracle's frames for exactly the whole samples it was sent."""
+    exe = san[variant]["opv-rx-bridge"]
+    raw = iq10.tobytes()
+    cut = (3 * 86720 + 12345) * 4 + 2                    # stdin ends inside a sample
+    f1 = tmp_path / "a.iq"
+    f1.write_bytes(raw[: 5 * 86720 * 4] + b"\x01\x02\x03")
+    base, socks = _udp_listeners(4)
+    p_udp, p_udp_empty = _free_udp_port(), _free_udp_port()
+    p = subprocess.Popen([exe, "-P", str(base), "--devices", "0,1", "--gather", "-", str(f1), f"udp:{p_udp}", f"udp:{p_udp_empty}"],
+                         stdin=subprocess.PIPE, stderr=subprocess.PIPE, env=SAN_ENV)
+
+    def feed_udp():
+        time.sleep(1.0)
+        tx = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        sizes, at, k = [1, 2, 3, 5, 1001, 65507, 8190], 0, 0
+        data = raw[: 4 * 86720 * 4 + 1]                  # ... and one stray byte before the end marker
+        while at < len(data):
+            n = sizes[k % len(sizes)]
+            tx.sendto(data[at:at + n], ("127.0.0.1", p_udp))
+            at += n
+            k += 1
+            time.sleep(0.002 if n > 1000 else 0.0)
+        tx.sendto(b"", ("127.0.0.1", p_udp))
+        tx.sendto(b"", ("127.0.0.1", p_udp_empty))
+        tx.close()
+    th = threading.Thread(target=feed_udp)
+    th.start()
+    at = k = 0
+    sizes = [16384, 1, 3, 70000, 2]
+    while at < cut:
+        n = min(sizes[k % len(sizes)], cut - at)
+        p.stdin.write(raw[at:at + n])
+        p.stdin.flush()
+        at += n
+        k += 1
+    p.stdin.close()
+    th.join()
+    err = p.stderr.read().decode(errors="replace")
+    rc = p.wait(timeout=600)
+    assert rc != 99 and "Sanitizer" not in err and "runtime error" not in err, err[-4000:]
+    assert rc == 0, err[-2000:]
+    assert "gather: 2 rank(s) x 2 stream(s)" in err and "0 stream(s) differ" in err
+    sent = [raw[: cut - cut % 4], raw[: 5 * 86720 * 4], raw[: 4 * 86720 * 4], b""]
+    for k in range(4):
+        got = []
+        while True:
+            try:
+                got.append(socks[k].recv(2048))
+            except BlockingIOError:
+                break
+        socks[k].close()
+        assert all(len(g) == 134 for g in got), k
+        exp = oracle.receive(np.frombuffer(sent[k], np.int16), streaming=True, want_soft=False)["frames"] if sent[k] else np.zeros((0, 134), np.uint8)
+        assert np.array_equal(np.frombuffer(b"".join(got), np.uint8).reshape(-1, 134), exp), (k, len(got), len(exp))
+
+
+def test_rx_bridge_refuses_bad_arguments_under_asan(san):
+    exe = san["asan"]["opv-rx-bridge"]
+    for args in (["--devices", "x,y"], ["--devices", "0,,1"], ["--devices", "-1"], ["--devices", ""], ["--devices", "0,1,"], ["--devices", "99999"],
+                 ["-P", "0"], ["-P", "65535", "-", "-"], ["-P", "-5"], ["/nonexistent/path.iq"], ["-H", "not-an-address", "-"]):
+        p = run([exe] + args, b"", timeout=60)
+        assert p.returncode == 2, (args, p.stderr[-300:])
+    assert run([exe, "-h"]).returncode == 0
+    p = run([exe, "-q"], b"\x00" * 1001, timeout=60)       # stdin only, no frames: exit 1 like opv-demod
+    assert p.returncode == 1
+
+
+def test_oracle_tx_and_decoder_edges_under_asan(san):
+    """the oracle's own code paths the CLIs above do not reach - coherent batch mode and a payload that the decoder drops - under ASan+UBSan
+    through the sanitized opv-demod (-c) and a silent capture"""
+    b = san["asan"]
+    sig = run([b["opv-mod"], "-S", "W5NYV", "-B", "3"]).stdout
+    p = run([b["opv-demod"], "-c", "-r", "-p", "35"], sig)
+    assert p.returncode in (0, 1) and b"PLL bandwidth: 35.0 Hz" in p.stderr
+    p = run([b["opv-demod"], "-r", "-q"], bytes(4 * 300000))
+    assert p.returncode == 1 and p.stdout == b""
