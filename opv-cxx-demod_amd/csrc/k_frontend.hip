@@ -234,11 +234,12 @@ __device__ __noinline__ double2 silence_pd(double dr, double di, PrevSums prv, b
 #include "opv_atan2.h"  // kOpvAtanTab (constant-memory image of the table) + host reference routine
 
 // ---- two-waves-per-stream mapping (ROLE 1 / 2 of msk_frontend_body): hand-over slots behind the atan table -------
-constexpr uint32_t kXchgPos = 0;      // 2 x {double pos; uint32 tag; pad}: position of symbol `tag`, written by the timing wave
+[[maybe_unused]] constexpr uint32_t kXchgPos = 0;      // 2 x {double pos; uint32 tag; pad}: position of symbol `tag`, written by the timing wave
 constexpr uint32_t kXchgFo = 32;      // 2 x {double fo;  uint32 tag; pad}: frequency for symbol `tag`, written by the AFC wave
-constexpr uint32_t kXchgBytes = 64;
-constexpr uint32_t kPollLimit = 1u << 22;   // a wave that has polled this often gives up: nothing can hang
+[[maybe_unused]] constexpr uint32_t kXchgBytes = 64;
+[[maybe_unused]] constexpr uint32_t kPollLimit = 1u << 22;   // a wave that has polled this often gives up: nothing can hang
 
+#ifdef OPV_WITH_COMPARISON_MAPPINGS
 // Wait until the {value, tag} slot at LDS address `a` carries `want`: one scalar loop (tag first, then the value - LDS
 // reads of a wave return in order, so a matching tag guarantees the value written before it).
 __device__ inline void role_await(uint32_t a, uint32_t want, double& v, uint32_t& timeouts) {
@@ -263,6 +264,7 @@ __device__ inline void role_await(uint32_t a, uint32_t want, double& v, uint32_t
     timeouts |= (cnt >= kPollLimit) ? 1u : 0u;
     v = val;
 }
+#endif
 
 // WPB = wavefronts (= streams) per workgroup. One wave per workgroup is the natural shape, but the dispatcher
 // places single-wave workgroups without regard to SIMDs: with 1024 of them on the chip's 1024 SIMDs, 88 SIMDs
@@ -307,7 +309,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     const double kf = (double)(jsamp - 10);
     const double kfs = kf * kDeltaPerHz;
     // T_1[i] = exp(-j 2 pi i / 160) = (cos(pi i/80), -sin(pi i/80)); zero outside a gate's window
-    double aE = 0, bE = 0, aO = 0, bO = 0, aL = 0, bL = 0;
+    [[maybe_unused]] double aE = 0, bE = 0, aO = 0, bO = 0, aL = 0, bL = 0;
     if constexpr (!RMAC) {
         double sn, cs;
         if (lane < 40) { sincospi((double)lane / 80.0, &sn, &cs); aE = cs; bE = -sn; }
@@ -407,7 +409,9 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %0, %2 offset:8" : : "v"(xchg + slot + ((tag & 1u) << 4)), "v"(v), "v"(tag) : "memory");
     };
     [[maybe_unused]] auto await = [&](uint32_t slot, uint32_t tag, double& v) {
+#ifdef OPV_WITH_COMPARISON_MAPPINGS
         role_await(xchg + slot + ((tag & 1u) << 4), uni(tag), v, timeouts);
+#endif
     };
     auto issue_tile = [&](uint32_t t) {
         // tile t -> slot t&1: 8 wave instructions; an even tile's first 16 B are mirrored into the
@@ -521,296 +525,9 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             fetch_read();
         };
 
-        // One symbol: correlate the fetched taps, run both loop filters, log the soft value, fetch
-        // the next symbol's taps. kFirst: first symbol of a demodulate() call, no AFC update
-        // (ref :289). `cur` receives this symbol's on-time sums and X[40], `prv` holds the
-        // previous symbol's.
-        // Order of events (pinned with sched_barriers; a lone wave only issues, it never overlaps):
-        //   1. on-time products -> reduce (4 values) -> v_readlane to every lane: soft, dominant tone
-        //   2. early/late products OF THE DOMINANT TONE ONLY (the tone is known by now: 4 values to
-        //      reduce instead of 8) -> reduce, the single DPP chain padded with the AFC operand
-        //      arithmetic -> 32 B through LDS, the round trip under the rest of that arithmetic
-        //   3. one reciprocal for both divides -> atan table row requested -> timing loop, soft
-        //      store, tap address under that LDS latency -> taps requested -> atan polynomial
-        auto symbol = [&](auto tag, PrevSums& cur, const PrevSums& prv) {
-            constexpr bool kFirst = decltype(tag)::first;   // first symbol of a call: no AFC update (ref :289)
-            constexpr bool kWide = decltype(tag)::wide;     // fo may still be an unclamped -o value
-            // ---- the lane's sample and LO factor ----------------------------------------------------
-            const int s0r = (int)(short)(w0 & 0xFFFF), s0i = w0 >> 16;      // ref :1023
-            const int d_r = (int)(short)(w1 & 0xFFFF) - s0r, d_i = (w1 >> 16) - s0i;
-            const double lr = fma(f, (double)d_r, (double)s0r);              // ref :122-128
-            const double li = fma(f, (double)d_i, (double)s0i);
-            if constexpr (ROLE == 1) await(kXchgFo, seq, fo);       // the frequency the AFC wave derived from symbol k-1
-            double xs, xc;
-            if constexpr (kWide) {
-                // -o takes any value (ref :1004-1005) and the AFC clamp (:303) first acts at the END of the
-                // call's second symbol: outside the polynomial's +/-2000 Hz range those two symbols take the
-                // full-range routine (their own instantiations; the steady-state body never tests for it)
-                if (__builtin_expect(uni_lt(2000.0, fabs(fo)), 0)) sincos(kfs * fo, &xs, &xc);
-                else expj_small(kfs, fo, sck, xs, xc);
-            } else {
-                expj_small(kfs, fo, sck, xs, xc);
-            }
-            // Z = Lam * conj(X)
-            const double zr = fma(lr, xc, li * xs);
-            const double zi = fma(li, xc, -(lr * xs));
-
-            // ---- 1. on-time gate: P1 = sum Zr a, P2 = sum Zi b, P3 = sum Zi a, P4 = sum Zr b ------
-            // Reduce-scatter over the wave (permlane32 / permlane16 swaps), row all-sum by DPP
-            // rotations, v_readlane to every lane. Swaps and DPP reads need one or two issue slots
-            // behind the VALU write of their source: the sigma-free halves of the early/late
-            // products, the X[40] hand-over (lane 50) and the soft-ring cursor fill them.
-            const double o1 = zr * aO, o2 = zi * bO, o3 = zi * aO, o4 = zr * bO;
-            [[maybe_unused]] double eA = 0, eB = 0, lA = 0, lB = 0;
-            if constexpr (kT) eA = zr * aE;
-            __builtin_amdgcn_sched_barrier(0);
-            const double r13 = swap32_add(o1, o3), r24 = swap32_add(o2, o4);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (kT) { eB = zi * aE; lA = zr * aL; }
-            __builtin_amdgcn_sched_barrier(0);
-            double q1 = swap16_add(r13, r24);                       // rows 0..3: P1o..P4o partials
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (kT) { lB = zi * aL; asm volatile("" : "+v"(lB)); }
-            if constexpr (kF) cur.x40c = readlane_d(xc, 50);
-            __builtin_amdgcn_sched_barrier(0);
-            q1 = dpp_add<0x128>(q1);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (kF) cur.x40s = readlane_d(xs, 50);
-            __builtin_amdgcn_sched_barrier(0);
-            q1 = dpp_add<0x124>(q1);
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t my_soft_off = soft_off;
-            soft_off = (soft_off + 8u) & soft_bmask;
-            asm volatile("" : "+v"(soft_off));                      // (empty asm: keeps the filler in its slot)
-            __builtin_amdgcn_sched_barrier(0);
-            q1 = dpp_add<0x122>(q1);
-            __builtin_amdgcn_sched_barrier(0);
-            [[maybe_unused]] double fo_sum_next = 0;
-            if constexpr (kF) { fo_sum_next = fo_sum + fo; asm volatile("" : "+v"(fo_sum_next)); }   // sum of the fo every symbol USED
-            __builtin_amdgcn_sched_barrier(0);
-            q1 = dpp_add<0x121>(q1);
-            __builtin_amdgcn_sched_barrier(0);
-            // (a v_readlane result may not be read by the next instructions: the values used first are read first)
-            double P2o = readlane_d(q1, 16), P4o = readlane_d(q1, 48);
-            const double P1o = readlane_d(q1, 0), P3o = readlane_d(q1, 32);
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" : "+v"(P2o), "+v"(P4o));                // one scalar source per instruction: these two in VGPRs
-            __builtin_amdgcn_sched_barrier(0);
-
-            // (kept as a difference of the two energies like the reference: the closed form
-            // 4 (P3 P4 - P1 P2) is three instructions instead of nine, but on inputs where the two
-            // tones tie - DC, a bare carrier - it breaks the tie differently from the reference)
-            const double s1r_ = P1o + P2o, s1i_ = P3o - P4o;        // S_1 (tone -13550)
-            const double s2r_ = P1o - P2o, s2i_ = P3o + P4o;        // S_2 (tone +13550)
-            const double en1 = fma(s1r_, s1r_, s1i_ * s1i_);        // ref :264-265
-            const double en2 = fma(s2r_, s2r_, s2i_ * s2i_);
-            const double soft = en2 - en1;                          // ref :268
-            // dominant tone: 1 iff e1 > e2 (ref :272 / :291), i.e. soft < 0 (a tie gives +0: tone 2).
-            // A gate's dominant correlation is C = (P1 + sg P2, P3 - sg P4), sg = +1 for tone 1,
-            // -1 for tone 2 = -copysign(1, soft): one bit-field insert, no compare.
-            nsg = mkd((dhi(soft) & (int)0x80000000) | 0x3ff00000, dlo(nsg));
-            const double sg = -nsg;
-
-            // ---- 2. early / late gates, dominant tone only: C = sum (Zr a + sg Zi b, Zi a - sg Zr b)
-            // Same reduction on 4 values; its slots are filled with the phase detector operands:
-            // dom * conj(prev) (ref :299). prev of the reference = S_prev advanced by one symbol of LO
-            // rotation, (-/+ j) X40_prev; applied to the product:
-            //   z = (S conj(S_prev)) * conj(X40_prev) * (+/- j)
-            // With the previous S scaled by sg (prs = sg pr, pis = sg pi) the (+/- j) becomes a fixed
-            // one: z = (cx, cy).
-            [[maybe_unused]] double wEr = 0, wEi = 0, wLr = 0, wLi = 0;
-            if constexpr (kT) {
-                const double szi = sg * zi, szr = sg * zr;
-                wEr = fma(szi, bE, eA); wEi = fma(-szr, bE, eB);
-                wLr = fma(szi, bL, lA); wLi = fma(-szr, bL, lB);
-            }
-            [[maybe_unused]] double ted = 0, pd = 0.0;
-            [[maybe_unused]] double dr = 0, di = 0, cx = 0, cy = 0, ax = 0, ay = 0, mx = 1.0, mn = 0, ratio = 0, dm_ = 1.0;
-            [[maybe_unused]] double2 c01{0, 0}, c23{0, 0}, c45{0, 0}, c67{0, 0};
-            [[maybe_unused]] double c8 = 0, h = 0;
-            [[maybe_unused]] double q2 = 0;
-            if constexpr (kFirst || ROLE == 1) {
-                if constexpr (kT) {
-                    const double hre = swap32_add(wEr, wLr), him = swap32_add(wEi, wLi);   // lanes <32: E, >=32: L
-                    q2 = swap16_add(hre, him);                      // rows: E.re, E.im, L.re, L.im partials
-                    q2 = dpp_add<0x128>(q2);
-                    q2 = dpp_add<0x124>(q2);
-                    q2 = dpp_add<0x122>(q2);
-                    q2 = dpp_add<0x121>(q2);
-                }
-            } else if constexpr (ROLE == 2) {
-                // the AFC wave: the phase detector's operands as one chain (no early / late reduction to hide in)
-                dr = fma(sg, P2o, P1o);
-                di = fma(-sg, P4o, P3o);
-                const double prs = fma(sg, prv.a, prv.b), pis = fma(sg, prv.c, -prv.d);
-                const double ar = fma(dr, prs, di * pis), ai = fma(di, prs, -(dr * pis));
-                cy = fma(ar, prv.x40c, ai * prv.x40s);              // Im z
-                cx = fma(ar, prv.x40s, -(ai * prv.x40c));           // Re z
-                ax = fabs(cx); ay = fabs(cy);
-                asm("v_max_f64 %0, |%3|, |%4|\n\tv_min_f64 %1, |%3|, |%4|\n\tv_max_f64 %2, %0, %5"
-                    : "=&v"(mx), "=&v"(mn), "=&v"(dm_) : "v"(cx), "v"(cy), "v"(kc_tiny));
-            } else {
-                dr = fma(sg, P2o, P1o);
-                asm volatile("" : "+v"(dr));
-                __builtin_amdgcn_sched_barrier(0);
-                const double hre = swap32_add(wEr, wLr), him = swap32_add(wEi, wLi);   // lanes <32: E, >=32: L
-                __builtin_amdgcn_sched_barrier(0);
-                di = fma(-sg, P4o, P3o);
-                double prs = fma(sg, prv.a, prv.b);
-                asm volatile("" : "+v"(di), "+v"(prs));
-                __builtin_amdgcn_sched_barrier(0);
-                q2 = swap16_add(hre, him);                          // rows: E.re, E.im, L.re, L.im partials
-                __builtin_amdgcn_sched_barrier(0);
-                double pis = fma(sg, prv.c, -prv.d);
-                double t_ar = di * pis;
-                asm volatile("" : "+v"(pis), "+v"(t_ar));
-                __builtin_amdgcn_sched_barrier(0);
-                q2 = dpp_add<0x128>(q2);
-                __builtin_amdgcn_sched_barrier(0);
-                double ar = fma(dr, prs, t_ar);
-                double t_ai = dr * pis;
-                asm volatile("" : "+v"(ar), "+v"(t_ai));
-                __builtin_amdgcn_sched_barrier(0);
-                q2 = dpp_add<0x124>(q2);
-                __builtin_amdgcn_sched_barrier(0);
-                double ai = fma(di, prs, -t_ai);
-                double t_cy = ai * prv.x40s;
-                asm volatile("" : "+v"(ai), "+v"(t_cy));
-                __builtin_amdgcn_sched_barrier(0);
-                q2 = dpp_add<0x122>(q2);
-                __builtin_amdgcn_sched_barrier(0);
-                cy = fma(ar, prv.x40c, t_cy);                       // Im z
-                double t_cx = ai * prv.x40c;
-                asm volatile("" : "+v"(cy), "+v"(t_cx));
-                __builtin_amdgcn_sched_barrier(0);
-                q2 = dpp_add<0x121>(q2);
-                __builtin_amdgcn_sched_barrier(0);
-                cx = fma(ar, prv.x40s, -t_cx);                      // Re z
-                ax = fabs(cx); ay = fabs(cy);
-                // max / min of the magnitudes with source modifiers (fmax(fabs(x), ..) costs a separate
-                // canonicalising v_max_f64 |x|, |x| first)
-                asm("v_max_f64 %0, |%3|, |%4|\n\tv_min_f64 %1, |%3|, |%4|\n\tv_max_f64 %2, %0, %5"
-                    : "=&v"(mx), "=&v"(mn), "=&v"(dm_) : "v"(cx), "v"(cy), "v"(kc_tiny));
-            }
-            [[maybe_unused]] double num = 0, den = 1.0;
-            if constexpr (kT) {
-                const double Eim = readlane_d(q2, 16), Lim = readlane_d(q2, 48);
-                const double Ere = readlane_d(q2, 0), Lre = readlane_d(q2, 32);
-                __builtin_amdgcn_sched_barrier(0);
-                const double ee = fma(Ere, Ere, Eim * Eim), el = fma(Lre, Lre, Lim * Lim);
-                num = el - ee; den = el + ee + kc_eps;              // ted = num/den (ref :275/:279)
-            }
-
-            // ---- 3. divides, timing loop, AFC ---------------------------------------------------------
-            if constexpr (kFirst || ROLE == 1) {
-                if constexpr (kT) {
-                    double y = __builtin_amdgcn_rcp(den);
-                    y = fma(fma(-den, y, 1.0), y, y);
-                    y = fma(fma(-den, y, 1.0), y, y);
-                    ted = num * y;
-                    ted = fma(fma(-den, ted, num), y, ted);
-                }
-            } else if constexpr (ROLE == 2) {
-                const double dm = dm_;                              // max(mx, 1e-100)
-                double y = __builtin_amdgcn_rcp(dm);
-                y = fma(fma(-dm, y, 1.0), y, y);
-                y = fma(fma(-dm, y, 1.0), y, y);
-                ratio = mn * y;
-                ratio = fma(fma(-dm, ratio, mn), y, ratio);
-                const double kd = rint(ratio * kc_32);
-                const int k = (int)kd;
-                h = fma(kd, kc_m1_32, ratio);
-                const unsigned char* rowb = reinterpret_cast<const unsigned char*>(atab) + __umul24((unsigned)k, kTabRow * 8u);
-                const double2* trow = reinterpret_cast<const double2*>(rowb);
-                c8 = reinterpret_cast<const double*>(rowb)[8]; c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
-            } else {
-                // the two divides of the symbol on one reciprocal: ted and mn/mx for the phase
-                // detector; den in [1e-10, 2e12], dm in [1e-100, 1e12]
-                const double dm = dm_;                              // max(mx, 1e-100); digital silence: 0/1e-100 = 0, fixed up below
-                const double tt = den * dm;
-                double y = __builtin_amdgcn_rcp(tt);
-                y = fma(fma(-tt, y, 1.0), y, y);
-                y = fma(fma(-tt, y, 1.0), y, y);
-                const double iden = y * dm, idm = y * den;
-                ratio = mn * idm;
-                ratio = fma(fma(-dm, ratio, mn), idm, ratio);
-                // atan2(cy, cx): table row by interval of ratio (the row's LDS latency is covered by
-                // the timing loop below)
-                const double kd = rint(ratio * kc_32);              // nearest expansion point k/32, k = 0..32
-                const int k = (int)kd;
-                h = fma(kd, kc_m1_32, ratio);                       // |h| <= 1/64
-                // row address by the full-rate 24-bit multiply (v_mul_lo_u32 is a quarter-rate instruction)
-                const unsigned char* rowb = reinterpret_cast<const unsigned char*>(atab) + __umul24((unsigned)k, kTabRow * 8u);
-                const double2* trow = reinterpret_cast<const double2*>(rowb);
-                c8 = reinterpret_cast<const double*>(rowb)[8]; c67 = trow[3]; c45 = trow[2]; c23 = trow[1]; c01 = trow[0];
-                ted = num * iden;
-                ted = fma(fma(-den, ted, num), iden, ted);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-
-            // ---- timing loop, soft log, next symbol's taps ------------------------------------------
-            if constexpr (kT) {
-            tf = clampd(fma(kc_beta, ted, tf), kc_ntfmax, kc_tfmax);  // beta (ref :118,:283-284)
-            // alpha (ref :117,:285). The reference then clamps to +/-2 (:286): |ted| < 1 (num = L - E, den = L + E + 1e-10,
-            // L, E >= 0) and |tf| <= 0.1, so |adj| <= 0.105 and that clamp can never act - it is not issued.
-            const double adj = fma(kc_alpha, ted, tf);
-            pos += 40.0 + adj;                                      // ref :313
-            if constexpr (kDual) publish(kXchgPos, pos, seq + 1u);  // the AFC wave is waiting for it
-            fetch_addr(pos, false);                                 // pos >= 38 after any symbol
-            __builtin_amdgcn_sched_barrier(0);
-            fetch_read();                                           // next symbol's taps requested as soon as their address exists
-            __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (kF) *(gdouble*)(soft_base + my_soft_off) = soft;   // all lanes, same value and address
-            [[maybe_unused]] double pd_off = 0;
-            if constexpr (!kFirst && kF) {
-                // cx < 0: pi - pd, as a +/-1 multiplier and a 0/pi offset built from the sign bit
-                sx = mkd((dhi(cx) & (int)0x80000000) | 0x3ff00000, dlo(sx));
-                pd_off = fma(-sx, kc_halfpi, kc_halfpi);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0xC17F);                 // lgkmcnt(1): the table row landed (LDS returns in order; only
-                __builtin_amdgcn_sched_barrier(0);                  //   the tap read, the newest operation, may still be in flight)
-            }
-
-            // ---- AFC ------------------------------------------------------------------------------
-            if constexpr (!kFirst && kF) {
-                pd = fma(c8, h, c67.y);                             // degree-8 Horner
-                pd = fma(pd, h, c67.x);
-                pd = fma(pd, h, c45.y);
-                pd = fma(pd, h, c45.x);
-                pd = fma(pd, h, c23.y);
-                pd = fma(pd, h, c23.x);
-                pd = fma(pd, h, c01.y);
-                pd = fma(pd, h, c01.x);
-                pd = (ay > ax) ? kc_halfpi - pd : pd;               // octant fix-up
-                pd = fma(sx, pd, pd_off);
-                pd = mkd((dhi(pd) & 0x7fffffff) | (dhi(cy) & (int)0x80000000), dlo(pd));  // sign of cy
-
-                if (__builtin_expect(uni_eq(mx, 0.0), 0)) {         // digital silence on either side
-                    const double2 sp = silence_pd(dr, di, prv, soft < 0.0, fo_sum, n_soft + (((my_soft_off - soft_off0) & soft_bmask) >> 3),
-                                                  P1o, P2o, P3o, P4o);
-                    pd = sp.x;
-                    edge_ties += uni((uint32_t)sp.y);
-                }
-            }
-            if constexpr (!kFirst && kF) {                          // ref :300-303
-                // (written as instructions: through fmin/fmax hipcc re-canonicalises the two loop-invariant
-                // bounds with a v_max_f64 x, x each, every symbol)
-                const double fo_new = fma(kc_gain, pd, fo);
-                asm("v_max_f64 %0, %1, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(fo) : "v"(fo_new), "v"(kc_nfomax), "v"(kc_fomax));
-            }
-            if constexpr (ROLE == 2) publish(kXchgFo, fo, seq + 1u);    // the timing wave needs it for the next symbol's LO
-            if constexpr (kF) {
-                fo_sum = fo_sum_next;                               // (the silence rule above needs the sum BEFORE this symbol)
-                // prev <- this symbol's on-time correlations (ref :309-310)
-                cur.a = P1o; cur.b = P2o; cur.c = P3o; cur.d = P4o;
-            }
-            if constexpr (kDual) ++seq;
-            if constexpr (ROLE == 2) {
-                await(kXchgPos, seq, pos);                          // the position this symbol led to (also the end-of-call test's)
-                fetch(pos, false);                                  // next symbol's taps (speculative at the end of a call)
-            }
-        };
+#ifdef OPV_WITH_COMPARISON_MAPPINGS
+#include "k_frontend_cmp_symbol.inc"   // `symbol`: the round-1 body + the two-waves-per-stream statements (comparison build only)
+#endif
 
         // The same symbol with the ROW-BROADCAST reduction (RMAC; ROLE 0 only). gfx950's DP-ALU DPP form
         //   v_fmac_f64_dpp acc, src0 row_newbcast:n, src1      acc[l] += src0[row(l), lane n] * src1[l]
@@ -1016,8 +733,13 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         };
 
         auto sym = [&](auto tag, PrevSums& cur, const PrevSums& prv) {
+#ifdef OPV_WITH_COMPARISON_MAPPINGS
             if constexpr (RMAC) symbol_r(tag, cur, prv);
             else symbol(tag, cur, prv);
+#else
+            static_assert(RMAC, "the product build carries the row-broadcast body only");
+            symbol_r(tag, cur, prv);
+#endif
         };
 
         if (uni_lt(pos + 40.0 + 10.0, Nd)) {               // ref :221
@@ -1099,6 +821,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     }
 }
 
+#ifdef OPV_WITH_COMPARISON_MAPPINGS   // the round-1 body under its two launch shapes (opv_set_frontend(ctx, -1)): comparison build only
 // atan table into LDS (shared by the workgroup's waves); the caller's barrier makes it visible
 template <int NT>
 __device__ __forceinline__ void load_atan_table(unsigned char* lds_tab) {
@@ -1121,7 +844,9 @@ extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_wg4(OpvStream* 
     __syncthreads();
     msk_frontend_body<4, 0>(streams, cfg, n_streams, lds_all);
 }
-// the same two launch shapes with the row-broadcast reduction (msk_frontend_body<.., 0, true>, `symbol_r`)
+#endif
+// the product front-end: one wave per stream, row-broadcast reduction (msk_frontend_body<.., 0, 1>, `symbol_r`), one or four
+// waves per workgroup
 constexpr uint32_t kAtanQBytes = 1025 * 32;
 template <int NT>
 __device__ __forceinline__ void load_atan_table_q(unsigned char* lds_tab) {
@@ -1142,6 +867,7 @@ extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_rb_wg4(OpvStrea
     __syncthreads();
     msk_frontend_body<4, 0, 1>(streams, cfg, n_streams, lds_all);
 }
+#ifdef OPV_WITH_COMPARISON_MAPPINGS
 // two waves per stream: wave 0 = timing loop (ROLE 1), wave 1 = AFC (ROLE 2), on two SIMDs of one CU
 extern "C" __global__ __launch_bounds__(128) void k_msk_frontend_dual(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
                                                                        int n_streams) {
@@ -1152,3 +878,4 @@ extern "C" __global__ __launch_bounds__(128) void k_msk_frontend_dual(OpvStream*
     if (threadIdx.x < 64) msk_frontend_body<1, 1>(streams, cfg, n_streams, lds_all);
     else msk_frontend_body<1, 2>(streams, cfg, n_streams, lds_all);
 }
+#endif

@@ -15,6 +15,10 @@
 #else
 #define OPV_HD
 #endif
+// Device images carry only what a kernel of that build reads: the 33-row table belongs to the comparison mappings
+// (-DOPV_WITH_COMPARISON_MAPPINGS), the 257-row and the first 1025-row table are host references (tests/test_atan2_host.py;
+// k_frontend_x4.hip keeps its own image of the 257-row one); the product's one-wave kernels read kOpvAtanTabQ3R.
+#if !defined(__HIP_DEVICE_COMPILE__) || defined(OPV_WITH_COMPARISON_MAPPINGS)
 #ifdef __HIP_DEVICE_COMPILE__
 __constant__
 #else
@@ -44,6 +48,7 @@ OPV_HD inline double opv_atan2(double y, double x) {
     if (x < 0) p = 3.14159265358979323846 - p;
     return y < 0 ? -p : p;
 }
+#endif
 
 // ---- the same angle without the octant fix-up (k_frontend.hip's row-broadcast body, k_frontend_x4.hip) -----------------
 // atan(|y| / |x|) = pi/4 + atan(q), q = (|y| - |x|) / (|y| + |x|) in [-1, 1]: 257 rows (k/128, |h| <= 1/256) of a degree-5
@@ -51,12 +56,8 @@ OPV_HD inline double opv_atan2(double y, double x) {
 // the octant. ABSOLUTE accuracy like opv_atan2 (max abs error vs glibc < 5e-16); the relative accuracy of tiny angles is
 // that of an angle near pi/4 (q near -1 cancels against the table's constant term) - the AFC integrates the angle, so the
 // absolute error counts. An argument on the positive x axis gives exactly 0 (row 0 starts with an exact 0 and h = 0).
-#ifdef __HIP_DEVICE_COMPILE__
-__constant__
-#else
-static const
-#endif
-double kOpvAtanTabQ[257][6] = {
+#ifndef __HIP_DEVICE_COMPILE__
+static const double kOpvAtanTabQ[257][6] = {
 #include "opv_atan_table_q.inc"
 };
 
@@ -82,12 +83,7 @@ OPV_HD inline double opv_atan2_q(double y, double x) {
 // the tables above: the AFC loop turns an angle error e into a steady-state frequency error of ~8600 e Hz (3e-10 Hz), and a soft
 // symbol moves by ~2e-8 of its size per Hz, i.e. by 1e-17: nothing the 1e-5 contract, the 1e-9 the tests assert or a quantiser
 // boundary can see. An argument on the positive x axis still gives exactly 0.
-#ifdef __HIP_DEVICE_COMPILE__
-__constant__
-#else
-static const
-#endif
-double kOpvAtanTabQ3[1025][4] = {
+static const double kOpvAtanTabQ3[1025][4] = {
 #include "opv_atan_table_q3.inc"
 };
 
@@ -104,6 +100,7 @@ OPV_HD inline double opv_atan2_q3(double y, double x) {
     if (x < 0) p = 3.14159265358979323846 - p;
     return y < 0 ? -p : p;
 }
+#endif  // !__HIP_DEVICE_COMPILE__
 
 // ---- and with the cubics written in the argument itself (what k_frontend.hip's row-broadcast body evaluates) --------------
 // Row k of kOpvAtanTabQ3R is row k of kOpvAtanTabQ3 re-expanded around 0: the same function values up to Horner's roundings

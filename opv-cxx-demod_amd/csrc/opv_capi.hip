@@ -21,9 +21,11 @@
 #include "opv_tx_internal.h"
 
 extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg, const double*);
+#ifdef OPV_WITH_COMPARISON_MAPPINGS   // `make variants`: the round-1 body and the two-waves-per-stream mapping (opv_set_frontend -1 / -2)
 extern "C" __global__ void k_msk_frontend(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_dual(OpvStream*, OpvGlobalCfg, int);
+#endif
 extern "C" __global__ void k_msk_frontend_rb(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_rb_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4(OpvStream*, OpvGlobalCfg, int);
@@ -539,13 +541,17 @@ extern "C" int opv_process(opv_ctx* c) {
         const double wn = c->cfg.pll_bw_hz * 2.0 * M_PI, zeta = 0.707, fsym = 2168000.0 / 40.0;   // set_pll_bandwidth (ref :551-558)
         c->last_frontend = "k_coherent_frontend";
         k_coherent_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, 2.0 * zeta * wn / fsym, wn * wn / (fsym * fsym));
-    } else if (c->frontend == -2) {                        // two waves per stream (opv_set_frontend(-2))
+    }
+#ifdef OPV_WITH_COMPARISON_MAPPINGS
+    else if (c->frontend == -2) {                          // two waves per stream (opv_set_frontend(-2))
         c->last_frontend = "k_msk_frontend_dual";
         k_msk_frontend_dual<<<S, 128, 0, c->stream>>>(c->d_streams, g, S);
     } else if (c->frontend == -1) {                        // one wave per stream, product + swap reductions (the round-1 body)
         if (S > kFrontendWg4MinStreams) { c->last_frontend = "k_msk_frontend_wg4"; k_msk_frontend_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S); }
         else { c->last_frontend = "k_msk_frontend"; k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g, S); }
-    } else if (x4 && S <= kFrontendX4Wg4MaxStreams) {      // up to two waves per SIMD: four waves (16 streams) per workgroup
+    }
+#endif
+    else if (x4 && S <= kFrontendX4Wg4MaxStreams) {      // up to two waves per SIMD: four waves (16 streams) per workgroup
         c->last_frontend = "k_msk_frontend_x4_wg4";
         k_msk_frontend_x4_wg4<<<(S + 15) / 16, 256, 0, c->stream>>>(c->d_streams, g, S);
     } else if (x4) {
@@ -580,8 +586,15 @@ extern "C" int opv_process(opv_ctx* c) {
 
 extern "C" int opv_set_frontend(opv_ctx* c, int streams_per_wave) {
     if (!c) return fail(OPV_EINVAL, "null context");
-    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4 && streams_per_wave != -1 && streams_per_wave != -2)
-        return fail(OPV_EINVAL, "opv_set_frontend: 0 (automatic), 1 or 4 streams per wave, -1 = one wave per stream with the product + swap reductions, -2 = two waves per stream");
+#ifdef OPV_WITH_COMPARISON_MAPPINGS
+    const bool cmp_ok = streams_per_wave == -1 || streams_per_wave == -2;
+#else
+    const bool cmp_ok = false;
+    if (streams_per_wave == -1 || streams_per_wave == -2)
+        return fail(OPV_EINVAL, "opv_set_frontend: the comparison mappings (-1, -2) are not part of this build (make variants)");
+#endif
+    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4 && !cmp_ok)
+        return fail(OPV_EINVAL, "opv_set_frontend: 0 (automatic), 1 or 4 streams per wave");
     c->frontend = streams_per_wave;
     return OPV_OK;
 }
