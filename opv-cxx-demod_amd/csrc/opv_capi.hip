@@ -576,7 +576,7 @@ extern "C" int opv_process(opv_ctx* c) {
     if (fr * (uint64_t)S > 0x7FFFFFFFull) return fail(OPV_EINVAL, "opv_process: streams x frames per round exceeds the grid limit");
     // the quantiser's scale (2144 dependent additions per frame) with one frame per lane, then one wave per frame
     k_frame_scale<<<(unsigned)((fr * (uint64_t)S + 63) / 64), 64, 0, c->stream>>>(c->d_streams, (uint32_t)fr, (uint32_t)S);
-    k_frame_decode<<<(unsigned)(fr * (uint64_t)S), 64, 0, c->stream>>>(c->d_streams, (uint32_t)fr);
+    k_frame_decode<<<(unsigned)(((fr + 1) / 2) * (uint64_t)S), 64, 0, c->stream>>>(c->d_streams, (uint32_t)((fr + 1) / 2));   // two frames per wave
     if (tm) { HIPCHK(hipEventRecord(c->ev[7], c->stream)); c->timing_valid = true; }
     k_collect_counts<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_counts, S, c->h_stall + slot);
     HIPCHK(hipEventRecord(c->done_ev, c->stream));
@@ -865,7 +865,7 @@ extern "C" int opv_decode_payloads(opv_ctx* c, const double* soft, size_t n, uin
         chk(hipMemcpyAsync(d_soft, soft, sizeof(double) * OPV_CODED * n, hipMemcpyHostToDevice, c->stream), "H2D soft");
         chk(hipMemsetAsync(d_out, 0, (size_t)OPV_FB * n, c->stream), "memset");
         k_payload_scale<<<(unsigned)((n + 63) / 64), 64, 0, c->stream>>>(d_soft, (uint32_t)n, d_scale);
-        k_decode_payloads<<<(unsigned)n, 64, 0, c->stream>>>(d_soft, (uint32_t)n, d_scale, d_out, d_met, d_q, d_d, d_b);
+        k_decode_payloads<<<(unsigned)((n + 1) / 2), 64, 0, c->stream>>>(d_soft, (uint32_t)n, d_scale, d_out, d_met, d_q, d_d, d_b);   // two payloads per wave
         chk(hipGetLastError(), "k_decode_payloads launch");
         chk(hipMemcpyAsync(out, d_out, (size_t)OPV_FB * n, hipMemcpyDeviceToHost, c->stream), "D2H out");
         chk(hipMemcpyAsync(metrics, d_met, sizeof(int32_t) * n, hipMemcpyDeviceToHost, c->stream), "D2H metrics");

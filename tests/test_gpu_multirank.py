@@ -237,18 +237,20 @@ def test_512_stream_context_vs_oracle():
     dm.process()
     dm.sync()
     host = d_iq.cpu().numpy()
-    o = Oracle()
+    from concurrent.futures import ProcessPoolExecutor
+    from soak_inputs import host_workers, oracle_receive_job
     total = guarded = 0
-    for k in range(S):
-        e = o.receive(host[k], streaming=True, want_soft=False)
-        fr, meta = dm.pop_frames(k)
-        assert np.array_equal(fr, e["frames"]), k
-        assert np.array_equal(meta["viterbi_metric"], e["metrics"]) and np.array_equal(meta["release_symbol"], e["frame_sym"]), k
-        events_match(amd, dm.pop_events(k), e["events"])
-        assert dm.state(k).est_offset_hz == e["est_offset"], k
-        no_ties(dm.state(k), f"stream {k} of 512", offset_ties=None)
-        guarded += dm.state(k).offset_ties > 0
-        total += len(fr)
+    with ProcessPoolExecutor(host_workers()) as pool:
+        exps = pool.map(oracle_receive_job, [host[k] for k in range(S)], chunksize=8)
+        for k, e in enumerate(exps):
+            fr, meta = dm.pop_frames(k)
+            assert np.array_equal(fr, e["frames"]), k
+            assert np.array_equal(meta["viterbi_metric"], e["metrics"]) and np.array_equal(meta["release_symbol"], e["frame_sym"]), k
+            events_match(amd, dm.pop_events(k), e["events"])
+            assert dm.state(k).est_offset_hz == e["est_offset"], k
+            no_ties(dm.state(k), f"stream {k} of 512", offset_ties=None)
+            guarded += dm.state(k).offset_ties > 0
+            total += len(fr)
     assert total >= S * (F - 1)
     print(f"offset-search near-tie guard fired on {guarded} of {S} streams (estimates equal the oracle's on all)")
     assert guarded <= 4
