@@ -96,13 +96,17 @@ __device__ __forceinline__ double payload_scale(const double* __restrict__ soft,
 // ---- packed 16-bit helpers: the two frames of a wave live in the two halves of every metric register ------------------
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b))); }
+typedef short ss2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sign(uint32_t a) { return __builtin_bit_cast(uint32_t, (ss2)(__builtin_bit_cast(ss2, a) >> 15)); }   // 0xFFFF per negative half
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
 
-constexpr int kBlk = 48;                                          // trellis steps per block: a multiple of the six phases, three 16-bit decision words
-constexpr int kTabSteps = 24;                                     // steps per branch-metric table refill
-constexpr int kDecWords = (OPV_FBITS / kBlk) * 3 * 64 + 64;       // 22 blocks x 3 words x 64 lanes + the 16-step tail: 4 288 words
-constexpr int kDecodeLds = 4 * kDecWords + 2 * OPV_FBITS + kTabSteps * 32;   // 17 152 + 2 144 + 768 = 20 064 B: eight workgroups (16 frames) per CU
-static_assert(OPV_FBITS == 16 + 22 * kBlk, "22 full blocks and a tail of 16 steps");
+constexpr int kTabSteps = 24;                                     // steps per branch-metric table refill (four groups of six)
+constexpr int kChunk = 96;                                        // steps per chunk: 16 groups of six = 16 six-bit fields = three words per frame
+constexpr int kChunks = OPV_FBITS / kChunk;                       // 11 full chunks; 16 steps remain (groups 176, 177 and the 4-step group 178)
+constexpr int kGroups = (OPV_FBITS + 5) / 6;                      // 179 pointer fields per frame
+constexpr int kDecWords = kChunks * 6 * 64 + 2 * 64;              // [chunk][frame][3][lane] + [frame][lane] for the remainder: 4 352 words
+constexpr int kDecodeLds = 4 * kDecWords + 2 * OPV_FBITS + kTabSteps * 32;   // 17 408 + 2 144 + 768 = 20 320 B: eight workgroups (16 frames) per CU
+static_assert(OPV_FBITS == kChunks * kChunk + 16 && kGroups == 16 * kChunks + 3, "11 chunks of 96 steps, then 6 + 6 + 4 steps");
 static_assert(8 * ((kDecodeLds + 511) / 512) * 512 <= 160 * 1024, "eight workgroups per CU");
 
 struct FrameIo {                      // one of the two frames of a wave
@@ -117,7 +121,7 @@ struct FrameIo {                      // one of the two frames of a wave
 // is 0x3FF0: a u32 add of two packed values never carries from A into B).
 __device__ __forceinline__ void decode_two(const FrameIo& A, const FrameIo& B, unsigned char* lds) {
     const int lane = threadIdx.x;
-    uint32_t* s_dec = reinterpret_cast<uint32_t*>(lds);                                   // 17 152 B decision words
+    uint32_t* s_dec = reinterpret_cast<uint32_t*>(lds);                                   // 17 408 B survivor pointer fields
     uint16_t* s_pair = reinterpret_cast<uint16_t*>(lds + 4 * kDecWords);                  //  2 144 B: step t -> A's two 3-bit values | B's << 8
     unsigned char* s_tab = lds + 4 * kDecWords + 2 * OPV_FBITS;                           //    768 B: 24 steps x 4 classes x {x, y}
     uint8_t* s_out = reinterpret_cast<uint8_t*>(s_pair);                                  // 2 x 136 B, over the value pairs once the trellis is done
@@ -130,25 +134,57 @@ __device__ __forceinline__ void decode_two(const FrameIo& A, const FrameIo& B, u
     if (!liveA && !liveB) return;
     // ---- quantise (ref :862-866: q=0 confident bit 0 ... q=7 confident bit 1) straight into the deinterleaved
     // position (ref :869-871): value i of the decoder's input is symbol deint_addr(i) of the payload; a lane does the
-    // pair (2 t, 2 t + 1) of trellis step t, for both frames
-    auto quantise = [&](const FrameIo& F, int t) -> unsigned {
-        unsigned pair = 0;
+    // pairs (2 t, 2 t + 1) of trellis steps t = lane, lane + 64, ... of one frame after the other.
+    // The reference's expression per value (:864-865) is int((-soft / scale) * 3.5 + 3.5 + 0.5), four rounded operations of which
+    // the IEEE division alone costs a wave ~30 fp64 instructions. Its result is decided by ONE multiply-add,
+    // x = fma(soft, -3.5 / scale, 4.0), whenever x is not within 1e-6 of an integer: both expressions are within ~1e-14 of
+    // the exact value 4 - 3.5 soft / scale for |x| < 9 (|soft / scale| <= 2144 always, so nothing overflows), hence they
+    // truncate alike unless the exact value is within 1e-14 of an integer - and then x is within the guard band and the
+    // reference's own sequence is evaluated (about one value in 10^5 on noise; every value of a few-level input). Outside
+    // (-1, 9) both clamp to the same end. NaN (never produced by the front-end) converts to 0 on both paths, like
+    // the reference's cvttsd2si + clamp.
+    // All of a frame's loads of a lane (34 gathered doubles, from L2 / HBM) are requested before the first is used: a wave
+    // that waited for them one trellis step at a time spent 30 000 cycles here (17 round trips), more than in the trellis.
+    auto quantise_frame = [&](const FrameIo& F, int byte_of_pair) {
+        constexpr int kIter = (OPV_FBITS + 63) / 64;              // 17 steps per lane (the last one for lanes < 48 only)
+        double sv[2 * kIter];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t i = 2u * (uint32_t)t + (uint32_t)h, a = deint_addr(i);
-            const double nrm = (-F.soft[(F.first + a) & F.mask] / F.scale) * 3.5 + 3.5;  // contraction is off for this TU
-            int v = (int)(nrm + 0.5);                                                  // C truncation toward zero
-            v = v < 0 ? 0 : (v > 7 ? 7 : v);
-            pair |= (unsigned)v << (4 * h);
-            if (F.tq) F.tq[a] = (int8_t)v;
-            if (F.td) F.td[i] = (int8_t)v;
+        for (int k = 0; k < kIter; ++k) {
+            const int t = lane + 64 * k;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t a = deint_addr(2u * (uint32_t)(t < OPV_FBITS ? t : 0) + (uint32_t)h);
+                sv[2 * k + h] = F.soft[(F.first + a) & F.mask];
+            }
         }
-        return pair;
+        const double inv = -3.5 / F.scale;
+#pragma unroll
+        for (int k = 0; k < kIter; ++k) {
+            const int t = lane + 64 * k;
+            if (t < OPV_FBITS) {
+                unsigned pair = 0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const uint32_t i = 2u * (uint32_t)t + (uint32_t)h, a = deint_addr(i);
+                    const double x = fma(sv[2 * k + h], inv, 4.0);
+                    int v = (int)x;
+                    if (__builtin_expect(fabs(x - rint(x)) < 1.0e-6 && x > -1.0 && x < 9.0, 0)) {
+                        const double nrm = (-sv[2 * k + h] / F.scale) * 3.5 + 3.5;         // contraction is off for this TU
+                        v = (int)(nrm + 0.5);                                              // C truncation toward zero
+                    }
+                    v = v < 0 ? 0 : (v > 7 ? 7 : v);
+                    pair |= (unsigned)v << (4 * h);
+                    if (F.tq) F.tq[a] = (int8_t)v;
+                    if (F.td) F.td[i] = (int8_t)v;
+                }
+                reinterpret_cast<uint8_t*>(s_pair)[2 * t + byte_of_pair] = (uint8_t)pair;
+            }
+        }
     };
-    for (int t = lane; t < OPV_FBITS; t += 64) {
-        const unsigned pa = liveA ? quantise(A, t) : 0u, pb = liveB ? quantise(B, t) : 0u;
-        s_pair[t] = (uint16_t)(pa | (pb << 8));
-    }
+    if (liveA) quantise_frame(A, 0);
+    else for (int t = lane; t < OPV_FBITS; t += 64) reinterpret_cast<uint8_t*>(s_pair)[2 * t] = 0;
+    if (liveB) quantise_frame(B, 1);
+    else for (int t = lane; t < OPV_FBITS; t += 64) reinterpret_cast<uint8_t*>(s_pair)[2 * t + 1] = 0;
     __syncthreads();
 
     // ---- add-compare-select, 1072 steps (ref :810-833), as XOR butterflies on packed metrics ------------------------
@@ -160,20 +196,27 @@ __device__ __forceinline__ void decode_two(const FrameIo& A, const FrameIo& B, u
     // has), the partner lane's own class is c ^ 2 and its other class c ^ 3.
     // Branch metrics: a step's two received values give four sums bm(j) = (j&2 ? 7-sg1 : sg1) + (j&1 ? 7-sg2 : sg2)
     // (:823-824) for BOTH frames (packed); 24 lanes build the tables of the next 24 steps in LDS - entry j = {bm(j),
-    // bm(j ^ flip)}, flip = 1 for the DPP phases and 3 for the swap phases - and every lane fetches ITS entry of a step with
-    // one ds_read_b64 (address = per-lane, per-phase constant + immediate): no per-step arithmetic on the received values.
-    //   K < 4  own = m + T.x;  oth = m[lane ^ (1 << K)] + T.y   (v_add_u32 with the DPP move folded in)
-    //          raw = sign(own - oth - beta), beta = 1 - u: "the own predecessor wins" with the tie rule in it
+    // bm(j ^ flip)}, flip = 1 for the DPP phases and 3 for the swap phases - and every lane fetches ITS entries of those steps
+    // (address = per-lane, per-phase constant + immediate) a whole group of 24 ahead: no arithmetic on the received values
+    // and no LDS round trip on the metric's dependency chain.
+    //   K < 4  x = m + T.x;  y = m[lane ^ (1 << K)] + T.y   (v_add_u32 with the DPP move folded in): own / other candidate
+    //          raw = sign(x - y - beta), beta = 1 - u: "x wins" with the tie rule in it
     //   K >= 4 a = m + T.x;  b = m + T.y;  v_permlane{16,32}_swap(a, b) puts own / other side by side: for lanes with
-    //          u = 0 (a, b) = (own, oth), for u = 1 (oth, own) - their table index is flipped so that each side received the
-    //          addend the partner needs; raw = sign(a - b - 1) is "own wins" for u = 0 and its complement for u = 1
-    //   m' = min of the two (v_pk_min_u16); the step's raw bit of both frames (bits 15 and 31) is shifted into a per-lane
-    //   16-step decision word (v_lshrrev + v_bfi) - no ballots, no lane-indexed writes.
+    //          u = 0 (x, y) = (own, other), for u = 1 (other, own) - their table index is flipped so that each side received the
+    //          addend the partner needs; raw = sign(x - y - 1) is again "x wins"
+    //   m' = min(x, y) (v_pk_min_u16).
+    // Survivors are kept as TRACE-FORWARD POINTERS, not as decision bits: register P holds, per frame, the lane this lane's
+    // survivor stood in at the last multiple of six steps. A step moves pointers exactly as it moves metrics - P' = raw ?
+    // Px : Py with Px / Py fetched by the same DPP move / swap as x / y (v_pk_ashrrev_i16 turns the two sign bits of the
+    // difference into select masks, one v_bfi_b32 selects for both frames) - and every sixth step P is filed as a 6-bit field
+    // (16 fields = 96 bits = three words per chunk of 96 steps, lane and frame) and reset to the lane's own number. The walk
+    // back then hops SIX steps per scalar round trip (below); with one decision bit per step it took one v_readlane -> scalar
+    // -> v_readlane round trip per step, 87 000 cycles a wave, more than the trellis itself.
     // Unreachable states carry 0x3FF0 instead of the reference's saturating 0x7FFFFFFF (:826-827): they vanish after six
     // steps (every state is reachable then), never win against a reachable one (those are <= 6 x 14 by then, and
-    // 0x3FF0 + 6 x 14 stays below 2^15 so that the 16-bit differences keep their sign), and their decisions are never
-    // visited by the traceback. Reachable metrics are <= 1072 x 14 = 15 008: 16 bits hold them and differences of them.
-    uint32_t tabofs[6], beta[4], flipm[3] = {0u, 0u, 0u};
+    // 0x3FF0 + 6 x 14 stays below 2^15 so that the 16-bit differences keep their sign), and their pointers are never
+    // followed by the walk. Reachable metrics are <= 1072 x 14 = 15 008: 16 bits hold them and differences of them.
+    uint32_t tabofs[6], beta[4];
 #pragma unroll
     for (int ph = 0; ph < 6; ++ph) {
         const int K = (5 - ph + 6) % 6, r = (ph + 1) % 6;
@@ -183,17 +226,12 @@ __device__ __forceinline__ void decode_two(const FrameIo& A, const FrameIo& B, u
         const int u = (lane >> K) & 1;                                        // == b0
         tabofs[ph] = (uint32_t)(((K >= 4 && u) ? (c ^ 3) : c) * 8);
         if (K < 4) beta[K] = u ? 0u : 0x00010001u;
-        // what the traceback wants from a decision bit is "the walk moves to the partner lane": !raw for K < 4,
-        // raw ^ !u for K >= 4 - folded into the stored words (slots 16 w + j of a block have phase (16 w + j) % 6)
-#pragma unroll
-        for (int w = 0; w < 3; ++w)
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if ((16 * w + j) % 6 == ph && (K < 4 || !u)) flipm[w] |= 0x00010001u << j;
     }
     uint32_t metric = (lane == 0) ? 0u : 0x3FF03FF0u;            // ref :805-806
-    uint32_t acc[3] = {0u, 0u, 0u};
-    const uint32_t kSignMask = 0x80008000u;
+    const uint32_t kIdent = (uint32_t)lane * 0x00010001u;        // "my survivor stood in this very lane", both frames
+    uint32_t ptr = kIdent;
+    const uint32_t kFifteen = 0x000F000Fu;                        // shift count of v_pk_ashrrev_i16, both halves
+    uint32_t fldA[3] = {0u, 0u, 0u}, fldB[3] = {0u, 0u, 0u};     // the chunk's 16 fields per frame
 
     auto build_tables = [&](int t0) {                             // steps t0 .. t0 + 23 (fewer at the tail), one per lane
         if (lane < kTabSteps && t0 + lane < OPV_FBITS) {
@@ -208,62 +246,105 @@ __device__ __forceinline__ void decode_two(const FrameIo& A, const FrameIo& B, u
             row[1] = make_uint4(bm2, swp ? bm1 : bm3, bm3, swp ? bm0 : bm2);
         }
     };
-    auto acs = [&](auto slot_tag) {
-        constexpr int SLOT = decltype(slot_tag)::value;           // step inside the block (blocks start on a multiple of six steps)
-        constexpr int PH = SLOT % 6, K = (5 - PH + 6) % 6, W = SLOT / 16;
-        const uint2 e = *reinterpret_cast<const uint2*>(s_tab + (SLOT % kTabSteps) * 32 + tabofs[PH]);
-        uint32_t x, y, bsub;
+    uint2 eA[kTabSteps], eB[kTabSteps];
+    auto fetch = [&](uint2 (&e)[kTabSteps]) {                     // this lane's entries of the 24 steps the table holds (it starts on a multiple of 6)
+#pragma unroll
+        for (int i = 0; i < kTabSteps; ++i) e[i] = *reinterpret_cast<const uint2*>(s_tab + i * 32 + tabofs[i % 6]);
+    };
+    auto acs = [&](auto slot_tag, const uint2 e) {
+        constexpr int SLOT = decltype(slot_tag)::value;           // step inside the chunk (chunks start on a multiple of six steps)
+        constexpr int PH = SLOT % 6, K = (5 - PH + 6) % 6;
+        uint32_t x, y, px, py, bsub;
         if constexpr (K < 4) {
             x = metric + e.x;
-            if constexpr (K == 0) y = (uint32_t)__builtin_amdgcn_mov_dpp((int)metric, 0xB1, 0xF, 0xF, true) + e.y;        // quad_perm [1,0,3,2]
-            else if constexpr (K == 1) y = (uint32_t)__builtin_amdgcn_mov_dpp((int)metric, 0x4E, 0xF, 0xF, true) + e.y;   // quad_perm [2,3,0,1]
-            else if constexpr (K == 3) y = (uint32_t)__builtin_amdgcn_mov_dpp((int)metric, 0x128, 0xF, 0xF, true) + e.y;  // row_ror:8
-            else {                                                 // lane ^ 4: banks 0, 2 read four lanes up, banks 1, 3 four lanes down
+            px = ptr;
+            if constexpr (K == 0) {                                // quad_perm [1,0,3,2]
+                y = (uint32_t)__builtin_amdgcn_mov_dpp((int)metric, 0xB1, 0xF, 0xF, true) + e.y;
+                py = (uint32_t)__builtin_amdgcn_mov_dpp((int)ptr, 0xB1, 0xF, 0xF, true);
+            } else if constexpr (K == 1) {                         // quad_perm [2,3,0,1]
+                y = (uint32_t)__builtin_amdgcn_mov_dpp((int)metric, 0x4E, 0xF, 0xF, true) + e.y;
+                py = (uint32_t)__builtin_amdgcn_mov_dpp((int)ptr, 0x4E, 0xF, 0xF, true);
+            } else if constexpr (K == 3) {                         // row_ror:8
+                y = (uint32_t)__builtin_amdgcn_mov_dpp((int)metric, 0x128, 0xF, 0xF, true) + e.y;
+                py = (uint32_t)__builtin_amdgcn_mov_dpp((int)ptr, 0x128, 0xF, 0xF, true);
+            } else {                                               // lane ^ 4: banks 0, 2 read four lanes up, banks 1, 3 four lanes down
+                const uint32_t m = metric, ey = e.y, p = ptr;     // (locals: asm operands cannot name captures of a generic lambda)
                 asm("v_add_u32_dpp %0, %1, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
                     "v_add_u32_dpp %0, %1, %2 row_shr:4 row_mask:0xf bank_mask:0xa"
-                    : "=&v"(y) : "v"(metric), "v"(e.y));
+                    : "=&v"(y) : "v"(m), "v"(ey));
+                asm("v_mov_b32_dpp %0, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                    "v_mov_b32_dpp %0, %1 row_shr:4 row_mask:0xf bank_mask:0xa"
+                    : "=&v"(py) : "v"(p));
             }
             bsub = beta[K];
         } else {
             x = metric + e.x;
             y = metric + e.y;
-            if constexpr (K == 4) { auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false); x = r[0]; y = r[1]; }
-            else { auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false); x = r[0]; y = r[1]; }
+            if constexpr (K == 4) {
+                auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false); x = r[0]; y = r[1];
+                auto q = __builtin_amdgcn_permlane16_swap(ptr, ptr, false, false); px = q[0]; py = q[1];
+            } else {
+                auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false); x = r[0]; y = r[1];
+                auto q = __builtin_amdgcn_permlane32_swap(ptr, ptr, false, false); px = q[0]; py = q[1];
+            }
             bsub = 0x00010001u;
         }
         const uint32_t d = pk_sub(pk_sub(x, y), bsub);
         metric = pk_min(x, y);
-        // the step's two sign bits (15 and 31) into the word, which moves down a place: step j of the word ends in bits j and 16 + j
-        // (locals: asm operands cannot name captures of a generic lambda)
-        const uint32_t sh = acc[W] >> 1, sm = kSignMask;
-        uint32_t merged;
-        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(merged) : "s"(sm), "v"(d), "v"(sh));
-        acc[W] = merged;
+        // 0xFFFF per frame whose x candidate won, then one select for both frames (as instructions: hipcc turns the C form
+        // into two 16-bit compares, two selects per half and a byte permute)
+        uint32_t xwins, sel;
+        const uint32_t k15 = kFifteen;                            // (locals: asm operands cannot name captures of a generic lambda)
+        asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(xwins) : "s"(k15), "v"(d));
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sel) : "v"(xwins), "v"(px), "v"(py));
+        ptr = sel;
+        if constexpr (PH == 5) {                                  // six steps done: file the pointer as field SLOT / 6, start afresh
+            constexpr int I = SLOT / 6, O = 6 * I, W = O / 32, SH = O % 32;
+            const uint32_t pa = ptr & 63u, pb = ptr >> 16;
+            fldA[W] |= pa << SH;
+            fldB[W] |= pb << SH;
+            if constexpr (SH > 26) { fldA[W + 1] |= pa >> (32 - SH); fldB[W + 1] |= pb >> (32 - SH); }
+            ptr = kIdent;
+        }
     };
-#define OPV_ACS6(G)                                                                                            \
-    acs(std::integral_constant<int, (G)>{}); acs(std::integral_constant<int, (G) + 1>{});                      \
-    acs(std::integral_constant<int, (G) + 2>{}); acs(std::integral_constant<int, (G) + 3>{});                  \
-    acs(std::integral_constant<int, (G) + 4>{}); acs(std::integral_constant<int, (G) + 5>{})
-    for (int blk = 0; blk < OPV_FBITS / kBlk; ++blk) {
-        build_tables(blk * kBlk);
+#define OPV_ACS6(G, E, O)                                                                                                          \
+    acs(std::integral_constant<int, (G)>{}, E[(G) - (O)]); acs(std::integral_constant<int, (G) + 1>{}, E[(G) + 1 - (O)]);          \
+    acs(std::integral_constant<int, (G) + 2>{}, E[(G) + 2 - (O)]); acs(std::integral_constant<int, (G) + 3>{}, E[(G) + 3 - (O)]);  \
+    acs(std::integral_constant<int, (G) + 4>{}, E[(G) + 4 - (O)]); acs(std::integral_constant<int, (G) + 5>{}, E[(G) + 5 - (O)])
+#define OPV_ACS24(G, E) OPV_ACS6(G, E, G); OPV_ACS6((G) + 6, E, G); OPV_ACS6((G) + 12, E, G); OPV_ACS6((G) + 18, E, G)
+    // software pipeline over groups of 24 steps: while a group runs from registers, the next group's tables are built and read
+    auto refill = [&](uint2 (&e)[kTabSteps], int t0) {
+        __syncthreads();                                          // (a single wave: orders this lane's earlier reads before the rows are rewritten)
+        build_tables(t0);
         __syncthreads();
-        OPV_ACS6(0); OPV_ACS6(6); OPV_ACS6(12); OPV_ACS6(18);
-        __syncthreads();                                          // every lane has read its entries of the first 24 steps
-        build_tables(blk * kBlk + kTabSteps);
-        __syncthreads();
-        OPV_ACS6(24); OPV_ACS6(30); OPV_ACS6(36); OPV_ACS6(42);
-        __syncthreads();
+        fetch(e);
+    };
+    refill(eA, 0);
+    for (int c = 0; c < kChunks; ++c) {
+        const int t0 = c * kChunk;
+        refill(eB, t0 + 24);
+        OPV_ACS24(0, eA);
+        refill(eA, t0 + 48);
+        OPV_ACS24(24, eB);
+        refill(eB, t0 + 72);
+        OPV_ACS24(48, eA);
+        refill(eA, t0 + 96);                                      // (the last chunk: the 16 steps of the remainder)
+        OPV_ACS24(72, eB);
 #pragma unroll
-        for (int w = 0; w < 3; ++w) s_dec[(blk * 3 + w) * 64 + lane] = acc[w] ^ flipm[w];
+        for (int w = 0; w < 3; ++w) {
+            s_dec[(c * 6 + w) * 64 + lane] = fldA[w];
+            s_dec[(c * 6 + 3 + w) * 64 + lane] = fldB[w];
+            fldA[w] = 0u; fldB[w] = 0u;
+        }
     }
-    {
-        build_tables(OPV_FBITS - 16);
-        __syncthreads();
-        OPV_ACS6(0); OPV_ACS6(6);
-        acs(std::integral_constant<int, 12>{}); acs(std::integral_constant<int, 13>{});
-        acs(std::integral_constant<int, 14>{}); acs(std::integral_constant<int, 15>{});
-        s_dec[(OPV_FBITS / kBlk) * 3 * 64 + lane] = acc[0] ^ flipm[0];
+    {   // steps 1056 .. 1071: groups 176 and 177, then the four steps of group 178 (fields 0, 1, 2 of a last word)
+        OPV_ACS6(0, eA, 0); OPV_ACS6(6, eA, 0);
+        acs(std::integral_constant<int, 12>{}, eA[12]); acs(std::integral_constant<int, 13>{}, eA[13]);
+        acs(std::integral_constant<int, 14>{}, eA[14]); acs(std::integral_constant<int, 15>{}, eA[15]);
+        s_dec[(kChunks * 6) * 64 + lane] = fldA[0] | ((ptr & 63u) << 12);
+        s_dec[(kChunks * 6 + 1) * 64 + lane] = fldB[0] | ((ptr >> 16) << 12);
     }
+#undef OPV_ACS24
 #undef OPV_ACS6
     __syncthreads();
 
@@ -279,58 +360,64 @@ __device__ __forceinline__ void decode_two(const FrameIo& A, const FrameIo& B, u
         if (pm < bmB || (pm == bmB && ps < bsB)) { bmB = pm; bsB = ps; blB = pl; }
     }
 
-    // ---- traceback + pack (ref :839-843, :878-884) on the SCALAR unit, both frames interleaved ----------------
-    // In lane space: step t's decision word of lane `cur` (one v_readlane with a scalar lane select) says whether the walk
-    // moves to the partner lane, cur ^= bit << K - three scalar instructions per step and frame. The decoded bit of step t
-    // is bit K of the lane the walk stands on (bits[t] = s % 2, :841), and a step changes bit K only: the six bits of `cur`
-    // at a step with K = 0 ARE the next six decoded bits in walk order, so the output accumulates 6 bits at a time. Walk
-    // order = bit order of the packer (byte 0 bit 0 is t = 1071, :878-884). Bytes go to LDS still randomised; the LFSR
-    // table is applied by all lanes at once on the way out.
+    // ---- the walk back + pack (ref :839-843, :878-884), six steps per hop, both frames interleaved ----------------
+    // In lane space a step changes bit K of the lane the walk stands on, and the decoded bit of that step IS that bit before
+    // the change (bits[t] = s % 2, :841); K runs 0, 1, .. 5 over the six steps below a multiple of six. So the six decoded
+    // bits of a hop are the six bits of the lane it starts from, in walk order, and the hop itself is one field lookup:
+    // v_readlane (scalar lane select) + s_bfe. Walk order = bit order of the packer (byte 0 bit 0 is t = 1071, :878-884).
+    // Bytes go to LDS still randomised; the LFSR table is applied by all lanes at once on the way out.
     uint32_t curA = uni32((uint32_t)blA), curB = uni32((uint32_t)blB);
     uint8_t* s_outA = s_out;
     uint8_t* s_outB = s_out + 136;
     uint8_t* const tbA = liveA ? A.tb : nullptr;                  // parity tap: the 1072 hard decisions (null in the product path)
     uint8_t* const tbB = liveB ? B.tb : nullptr;
-    {   // the 16 steps t = 1071 .. 1056 (slots 15 .. 0 of the tail word): two bytes, bit by bit
-        const int wv = (int)s_dec[(OPV_FBITS / kBlk) * 3 * 64 + lane];
-        uint32_t oa = 0, ob = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int slot = 15 - j, K = (5 - slot % 6 + 6) % 6;
-            oa |= ((curA >> K) & 1u) << j;
-            ob |= ((curB >> K) & 1u) << j;
-            if (tbA) { if (lane == 0) tbA[OPV_FBITS - 1 - j] = (uint8_t)((curA >> K) & 1u); }
-            if (tbB) { if (lane == 0) tbB[OPV_FBITS - 1 - j] = (uint8_t)((curB >> K) & 1u); }
-            const uint32_t wa = (uint32_t)__builtin_amdgcn_readlane(wv, (int)curA), wb = (uint32_t)__builtin_amdgcn_readlane(wv, (int)curB);
-            curA ^= ((wa >> slot) & 1u) << K;
-            curB ^= ((wb >> (16 + slot)) & 1u) << K;
-        }
+    {   // t = 1071 .. 1056: the 4-step group (K = 2, 3, 4, 5: bits 2..5 of the end lane), then groups 177 and 176
+        const int wa = (int)s_dec[(kChunks * 6) * 64 + lane], wb = (int)s_dec[(kChunks * 6 + 1) * 64 + lane];
+        uint32_t oa = curA >> 2, ob = curB >> 2;
+        curA = __builtin_amdgcn_ubfe((uint32_t)__builtin_amdgcn_readlane(wa, (int)curA), 12u, 6u);
+        curB = __builtin_amdgcn_ubfe((uint32_t)__builtin_amdgcn_readlane(wb, (int)curB), 12u, 6u);
+        oa |= curA << 4; ob |= curB << 4;
+        curA = __builtin_amdgcn_ubfe((uint32_t)__builtin_amdgcn_readlane(wa, (int)curA), 6u, 6u);
+        curB = __builtin_amdgcn_ubfe((uint32_t)__builtin_amdgcn_readlane(wb, (int)curB), 6u, 6u);
+        oa |= curA << 10; ob |= curB << 10;
+        curA = __builtin_amdgcn_ubfe((uint32_t)__builtin_amdgcn_readlane(wa, (int)curA), 0u, 6u);
+        curB = __builtin_amdgcn_ubfe((uint32_t)__builtin_amdgcn_readlane(wb, (int)curB), 0u, 6u);
         if (lane < 2) { s_outA[lane] = (uint8_t)(oa >> (8 * lane)); s_outB[lane] = (uint8_t)(ob >> (8 * lane)); }
-    }
-    for (int blk = OPV_FBITS / kBlk - 1; blk >= 0; --blk) {
-        int wv[3];
-#pragma unroll
-        for (int w = 0; w < 3; ++w) wv[w] = (int)s_dec[(blk * 3 + w) * 64 + lane];
-        unsigned long long oa = 0, ob = 0;                       // 48 decoded bits per frame in walk order
-#pragma unroll
-        for (int j = 0; j < kBlk; ++j) {
-            const int slot = kBlk - 1 - j, K = (5 - slot % 6 + 6) % 6;
-            if (j % 6 == 0) {                                     // K == 0 here: the walk's next six bits
-                oa |= (unsigned long long)curA << j;
-                ob |= (unsigned long long)curB << j;
-            }
-            const uint32_t wa = (uint32_t)__builtin_amdgcn_readlane(wv[slot / 16], (int)curA);
-            const uint32_t wb = (uint32_t)__builtin_amdgcn_readlane(wv[slot / 16], (int)curB);
-            curA ^= ((wa >> (slot % 16)) & 1u) << K;
-            curB ^= ((wb >> (16 + slot % 16)) & 1u) << K;
+        if (lane < 16) {
+            if (tbA) tbA[OPV_FBITS - 1 - lane] = (uint8_t)((oa >> lane) & 1u);
+            if (tbB) tbB[OPV_FBITS - 1 - lane] = (uint8_t)((ob >> lane) & 1u);
         }
-        const int byte0 = 2 + 6 * (OPV_FBITS / kBlk - 1 - blk);
-        if (lane < 6) { s_outA[byte0 + lane] = (uint8_t)(oa >> (8 * lane)); s_outB[byte0 + lane] = (uint8_t)(ob >> (8 * lane)); }
-        if (tbA || tbB) {                                         // the 48 decisions of this block, one per lane
-            const int t = blk * kBlk + kBlk - 1 - lane;
-            if (lane < kBlk) {
-                if (tbA) tbA[t] = (uint8_t)((oa >> lane) & 1u);
-                if (tbB) tbB[t] = (uint8_t)((ob >> lane) & 1u);
+    }
+    for (int c = kChunks - 1; c >= 0; --c) {
+        int wa[3], wb[3];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { wa[w] = (int)s_dec[(c * 6 + w) * 64 + lane]; wb[w] = (int)s_dec[(c * 6 + 3 + w) * 64 + lane]; }
+        uint32_t oa[3] = {0u, 0u, 0u}, ob[3] = {0u, 0u, 0u};     // 96 decoded bits per frame in walk order
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {                            // hop j starts at time t0 + 96 - 6 j and uses field 15 - j
+            const int o = 6 * j, ow = o / 32, osh = o % 32;
+            oa[ow] |= curA << osh; ob[ow] |= curB << osh;
+            if (osh > 26) { oa[ow + 1] |= curA >> (32 - osh); ob[ow + 1] |= curB >> (32 - osh); }
+            const int f = 6 * (15 - j), fw = f / 32, fsh = f % 32;
+            uint32_t na = (uint32_t)__builtin_amdgcn_readlane(wa[fw], (int)curA) >> fsh;
+            uint32_t nb = (uint32_t)__builtin_amdgcn_readlane(wb[fw], (int)curB) >> fsh;
+            if (fsh > 26) {
+                na |= (uint32_t)__builtin_amdgcn_readlane(wa[fw + 1], (int)curA) << (32 - fsh);
+                nb |= (uint32_t)__builtin_amdgcn_readlane(wb[fw + 1], (int)curB) << (32 - fsh);
+            }
+            curA = na & 63u; curB = nb & 63u;
+        }
+        const int byte0 = 2 + 12 * (kChunks - 1 - c);
+        if (lane < 12) {
+            const int w = lane >> 2, sh = 8 * (lane & 3);
+            s_outA[byte0 + lane] = (uint8_t)((w == 0 ? oa[0] : w == 1 ? oa[1] : oa[2]) >> sh);
+            s_outB[byte0 + lane] = (uint8_t)((w == 0 ? ob[0] : w == 1 ? ob[1] : ob[2]) >> sh);
+        }
+        if (tbA || tbB) {                                         // the 96 decisions of this chunk
+            for (int j = lane; j < kChunk; j += 64) {
+                const int t = c * kChunk + kChunk - 1 - j, w = j >> 5, sh = j & 31;
+                if (tbA) tbA[t] = (uint8_t)(((w == 0 ? oa[0] : w == 1 ? oa[1] : oa[2]) >> sh) & 1u);
+                if (tbB) tbB[t] = (uint8_t)(((w == 0 ? ob[0] : w == 1 ? ob[1] : ob[2]) >> sh) & 1u);
             }
         }
     }

@@ -93,6 +93,59 @@ def decode(q):
     return best, bits
 
 
+def decode_trace_forward(q):
+    """the same trellis with TRACE-FORWARD pointers instead of decision bits (the kernel's final form): every lane carries the
+    lane its survivor stood in at the last multiple of six steps; a step moves pointers exactly as it moves metrics (the
+    winner's pointer, fetched from the same partner lane), every sixth step the pointer is filed as a 6-bit field and reset to
+    the lane's own number. The walk back then hops six steps per field, and the six decoded bits of a hop are the bits of the
+    lane it starts from (a step changes bit K of the lane only, K runs 0..5 in walk order from a multiple of six)."""
+    tabs = lane_tables()
+    M = np.full(64, SENT, np.int64)
+    M[0] = 0
+    lanes = np.arange(64)
+    P = lanes.copy()
+    fields = []
+    for t in range(1072):
+        K, u, idx = tabs[t % 6]
+        sg1, sg2 = int(q[2 * t]), int(q[2 * t + 1])
+        bm = np.array([(7 - sg1 if j & 2 else sg1) + (7 - sg2 if j & 1 else sg2) for j in range(4)])
+        flip = 3 if K >= 4 else 1
+        X, Y = bm[idx], bm[idx ^ flip]
+        if K < 4:
+            x = M + X
+            y = M[lanes ^ (1 << K)] + Y
+            raw = (x - y - (1 - u)) < 0
+            Px, Py = P, P[lanes ^ (1 << K)]
+        else:
+            a, b = M + X, M + Y
+            x, y = a.copy(), b.copy()
+            Px, Py = P.copy(), P.copy()
+            odd = ((lanes >> K) & 1) == 1
+            x[odd] = b[lanes[odd] ^ (1 << K)]
+            y[~odd] = a[lanes[~odd] ^ (1 << K)]
+            Px[odd] = P[lanes[odd] ^ (1 << K)]
+            Py[~odd] = P[lanes[~odd] ^ (1 << K)]
+            raw = (x - y - 1) < 0
+        M = np.minimum(x, y)
+        P = np.where(raw, Px, Py)
+        if t % 6 == 5 or t == 1071:
+            fields.append(P.copy())
+            P = lanes.copy()
+    assert len(fields) == 179
+    states = np.array([rotl6(l, 1072 % 6) for l in range(64)])
+    cur = int(np.lexsort((states, M))[0])
+    best = int(M[cur])
+    walk = []                                      # decoded bits in walk order (t = 1071 first)
+    walk += [(cur >> k) & 1 for k in (2, 3, 4, 5)]  # the 4-step tail group: K = 2, 3, 4, 5
+    cur = int(fields[178][cur])
+    for g in range(177, -1, -1):
+        walk += [(cur >> k) & 1 for k in range(6)]
+        cur = int(fields[g][cur])
+    assert cur == 0                                 # the encoder starts in state 0 = lane 0 at time 0
+    bits = np.array(walk[::-1], np.uint8)
+    return best, bits
+
+
 def main():
     from oracle_lib import Oracle
     o = Oracle()
@@ -113,7 +166,9 @@ def main():
         m0, b0 = o.viterbi(q)
         m1, b1 = decode(q)
         assert m0 == m1 and np.array_equal(b0, b1), (trial, kind, m0, m1, int((b0 != b1).sum()))
-    print(f"{n} trellises: metric and 1072 bits equal the oracle's")
+        m2, b2 = decode_trace_forward(q)
+        assert m0 == m2 and np.array_equal(b0, b2), ("trace-forward", trial, kind, m0, m2, int((b0 != b2).sum()))
+    print(f"{n} trellises: metric and 1072 bits equal the oracle's, with decision bits and with trace-forward pointers")
 
 
 if __name__ == "__main__":
