@@ -10,28 +10,32 @@
 // |soft| in index order - 2144 dependent additions, which a wave-per-frame kernel can only run
 // redundantly on its 64 lanes (round 2: 4.8 k of the 35 k instructions of a frame). They now run in a
 // pre-pass with one FRAME per lane (k_frame_scale / k_payload_scale: 64 frames' sums side by side, same
-// additions in the same order), and the decoder reads the scale - then one IEEE divide, one multiply,
-// two adds and a truncation per symbol with FMA contraction disabled. Given the same 2144 doubles this
-// kernel returns the same bytes, decisions and metric as the reference, always.
+// additions in the same order), and the decoder reads the scale. The quantised value itself - one IEEE divide, one
+// multiply, two adds and a truncation per symbol in the reference, FMA contraction disabled - is decided by ONE multiply-add
+// wherever that provably gives the same integer, and by the reference's own sequence inside a guard band around the
+// quantiser's boundaries (decode_two). Given the same 2144 doubles this kernel returns the same bytes, decisions and
+// metric as the reference, always.
 //
-// Viterbi on a wave: the 64 path metrics live one per lane (int32) under a ROTATING state-to-lane
-// map (state s at time t in lane rotr6(s, t)), which turns the trellis step into an XOR butterfly:
-// the two predecessors of the state a lane will hold are the lane itself and lane ^ (1 << k),
-// k = (5 - t) mod 6 - one DPP quad_perm / row shift / v_permlane*_swap per step, no LDS-crossbar
-// permute on the step's dependency chain. G1=0x4F has no tap on state bit 5, G2=0x6D has, so the
-// other predecessor flips e2 only; the own predecessor's (e1, e2) are per-lane constants for each of
-// the six phases. Add-compare-select with the reference's tie rule (m0 <= m1 -> lower predecessor,
-// :829); the 64 decision bits of a step are two ballots -> one 64-bit word in LDS (1072 x 8 B =
-// 8.6 KB/frame instead of the reference's 68.6 KB byte matrix). Traceback is a serial walk over those
-// words in lane space from the first-minimum end state (:835-843), emitting bytes
-// MSB-of-byte-133-first exactly as the packer does (:878-884), XORed with the LFSR table
+// Viterbi on a wave, TWO frames per wave (round 4): the 64 path metrics of a frame live one per lane under a ROTATING
+// state-to-lane map (state s at time t in lane rotr6(s, t)), frame A in the low 16 bits of the register and frame B in
+// the high 16 bits (metrics stay below 15 008 + 14, so packed 16-bit adds / min serve both). The rotating map turns the
+// trellis step into an XOR butterfly: the two predecessors of the state a lane will hold are the lane itself and
+// lane ^ (1 << k), k = (5 - t) mod 6 - a DPP modifier on the add (k < 4) or one v_permlane{16,32}_swap of the two candidate
+// registers (k >= 4), no LDS-crossbar permute and no select on the step's dependency chain. Branch metrics come from
+// per-step class tables in LDS (four sums of the step's two received values, both frames packed), read a group of 24 steps
+// ahead. Add-compare-select with the reference's tie rule (m0 <= m1 -> lower predecessor, :829). Survivors are kept as
+// trace-forward pointers (the lane a lane's survivor stood in six steps ago, 6 bits per six steps = the same 8.6 KB per
+// frame as one decision bit per step; the reference keeps a 68.6 KB byte matrix), so the walk back from the
+// first-minimum end state (:835-843) hops six steps per scalar round trip and reads its six decoded bits off the lane
+// number. Bytes are emitted MSB-of-byte-133-first exactly as the packer does (:878-884) and XORed with the LFSR table
 // (:887-895; the LFSR restarts at 0xFF every frame so it is a constant 134-byte table).
-// (The index algebra was checked against the oracle's decoder in a numpy model before it was written.)
+// The index algebra was checked against the oracle's decoder in a numpy model before the kernel was written
+// (scripts/models/viterbi_packed_model.py: decision-bit and trace-forward forms).
 //
 // Bytes: 17 152 B of soft symbols in (read twice: pre-pass and quantiser, the second time from L2), 134 B out per
-// frame. With the scale known up front the soft doubles are never staged in LDS: a lane quantises straight into the
-// deinterleaved position (a gather of 8-byte words inside the frame's 17 KB; a trellis step's two 3-bit values share a
-// byte), and a frame needs 9.8 KB of LDS instead of 17.3 KB - sixteen frames per CU (four waves per SIMD) instead of nine. Integer ACS rate: 68 608 ACS/frame. No MFMA.
+// frame. The soft doubles are never staged in LDS: a lane quantises straight into the deinterleaved position (a gather of
+// 8-byte words inside the frame's 17 KB; a trellis step's two 3-bit values share a byte). A wave needs 20.3 KB of LDS:
+// eight workgroups = sixteen frames per CU. Integer ACS rate: 68 608 ACS/frame. No MFMA.
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -79,13 +83,23 @@ __device__ __forceinline__ double payload_scale(const double* __restrict__ soft,
     double sum = 0.0;
     first &= mask;
     if ((uint64_t)first + OPV_CODED - 1u <= (uint64_t)mask) {
+        // sixteen 16-byte loads per batch, and the next batch is requested before this one is summed (64 lanes walk 64
+        // payloads: nothing but the lane's own requests hides the memory latency; with eight loads in flight and none
+        // ahead, a lone round of 64 frames spent 68 us here, ten times the 2144 dependent additions)
         const double2u* p = reinterpret_cast<const double2u*>(soft + first);
-        for (uint32_t i = 0; i < OPV_CODED / 2; i += 8) {
-            double2u v[8];
+        constexpr uint32_t kB = 16, kN = OPV_CODED / 2 / kB;                                // 67 batches
+        static_assert(kB * kN * 2 == OPV_CODED, "batches tile the payload");
+        double2u cur[kB], nxt[kB];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = p[i + j];                                 // eight loads in flight
+        for (uint32_t j = 0; j < kB; ++j) cur[j] = p[j];
+        for (uint32_t b = 0; b < kN; ++b) {
+            const uint32_t nb = b + 1 < kN ? b + 1 : b;                                     // (the last trip re-reads its own batch)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { sum += fabs(v[j].x); sum += fabs(v[j].y); }    // strictly in index order, like the reference's loop
+            for (uint32_t j = 0; j < kB; ++j) nxt[j] = p[nb * kB + j];
+#pragma unroll
+            for (uint32_t j = 0; j < kB; ++j) { sum += fabs(cur[j].x); sum += fabs(cur[j].y); }    // strictly in index order, like the reference's loop
+#pragma unroll
+            for (uint32_t j = 0; j < kB; ++j) cur[j] = nxt[j];
         }
     } else {
         for (uint32_t i = 0; i < OPV_CODED; ++i) sum += fabs(soft[(first + i) & mask]);
