@@ -288,7 +288,7 @@ def main():
     cyc = np.array([w[2] for w in wi], np.float64)
     tick = np.array([w[3] for w in wi], np.float64)
     syms = np.array([st.total_symbols for st in states], np.float64)
-    per_wave = 4.0 if "_x4" in fe_kernel else 1.0         # streams sharing a wave (k_frontend_x4.hip)
+    per_wave = 16.0 if "_x16" in fe_kernel else 4.0 if "_x4" in fe_kernel else 1.0   # streams sharing a wave (k_frontend_x4.hip, k_frontend_x16.hip)
     live_cps = float(np.median(cyc / np.maximum(syms * per_wave, 1.0))) if cyc.min() > 0 else None
     live_clock = float(np.median(cyc / np.maximum(tick, 1.0)) * 100e6) if tick.min() > 0 else None
     collective = None
@@ -435,7 +435,7 @@ def main():
         one.close()
         # throughput-bound regime: many short streams carved out of the resident captures
         sweep = {}
-        for ns, nfr in ((128, 480), (192, 320), (256, 240), (512, 120), (1024, 60), (2048, 30), (4096, 15), (8192, 7)):
+        for ns, nfr in ((128, 480), (192, 320), (256, 240), (512, 120), (1024, 60), (2048, 30), (4096, 15), (8192, 7), (16384, 3)):
             if nfr > F:
                 continue
             per = F // nfr
@@ -445,8 +445,12 @@ def main():
             m = amd.Demod(ns, max_samples=sub_n + 64, streaming=True, device=dev_index)
             m.enable_timing(True)
             ent = {}
-            for spw in (1, 4):                          # streams per wavefront (opv_set_frontend)
+            for spw in (1, 4, 16):                      # streams per wavefront (opv_set_frontend)
                 if spw == 4 and ns < 4096:         # (the four-per-wave mapping is the automatic choice from 2049 streams on)
+                    continue
+                if spw == 16 and ns < 4096:        # (sixteen per wave: 1024 waves = one per SIMD need 16 384 streams)
+                    continue
+                if spw == 1 and ns > 8192:
                     continue
                 m.set_frontend(spw)
                 for rep in range(2):
@@ -568,6 +572,51 @@ def main():
                     torch.cuda.empty_cache()
             except Exception as e:                       # an extra must never cost the bench line
                 extras["configs4_workload_on_one_gpu"] = {"error": repr(e)[:300]}
+        # The many-stream regime on data of its own (not carved out of the 64 captures): 32 768 independent streams x 8 frames,
+        # every one its own BERT capture through the device channel (91 GB of IQ in HBM), one opv_process on the automatic
+        # mapping - sixteen streams per wavefront, two waves per SIMD (k_frontend_x16.hip). The only place where this path's
+        # HBM fraction is not negligible: reported with its own roofline figures.
+        if not args.no_big and S == 64:
+            try:
+                NS, NF = 32768, 8
+                n8 = amd.lib().opv_tx_modulated_samples(NF)
+                free_b, _tot = torch.cuda.mem_get_info()
+                need_b = NS * n8 * 4 * 1.05 + (12 << 30)
+                if free_b < need_b:
+                    extras["many_streams_unique_captures"] = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, {need_b / 1e9:.0f} GB needed"}
+                else:
+                    ms = amd.Demod(NS, max_samples=n8 + 64, streaming=True, device=dev_index)
+                    gt = {}
+                    d_ms, tx_ms, _n8 = workload.generate(amd, ms, torch, dev, range(NS), NF, args.ebn0, timing=gt)
+                    ms.enable_timing(True)
+                    for rep in range(2):
+                        ms.reset()
+                        for k in range(NS):
+                            ms.attach(k, d_ms[k].data_ptr(), n8, eof=True)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        ms.process()
+                        ms.sync()
+                        t1 = time.perf_counter() - t0
+                    fv, cv = workload.frame_views(ms, torch, dev)
+                    exp_m = torch.from_numpy(tx_ms).to(dev)
+                    n_bad = int((fv[:, :NF - 1, :] != exp_m[:, :NF - 1, :]).any(dim=2).sum().item())
+                    ktm = ms.kernel_times()
+                    fe_gbs = NS * n8 * ALGO_BYTES_PER_SAMPLE / (ktm["msk_frontend"] * 1e-3) / 1e9
+                    extras["many_streams_unique_captures"] = {
+                        "streams": NS, "frames_per_stream": NF, "iq_GB_in_hbm": round(NS * n8 * 4 / 1e9, 1), "generate_s": round(gt["generate_s"], 1),
+                        "frontend_kernel": ms.frontend_kernel(),
+                        "Msamples/s": round(NS * n8 / t1 / 1e6, 1), "x_realtime": round(NS * n8 / t1 / 2.168e6, 0), "ms": round(t1 * 1e3, 2),
+                        "frontend_alone_Msamples/s": round(NS * n8 / ktm["msk_frontend"] / 1e3, 1),
+                        "kernel_ms": {k: round(v, 3) for k, v in ktm.items()},
+                        "roofline_frontend": {"bound": "hbm", "achieved": round(fe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": round(fe_gbs / HBM_PEAK_GBS, 4)},
+                        "frames_released": int(cv.sum().item()), "frames_exact_of_first_7": NS * (NF - 1) - n_bad, "frames_compared": NS * (NF - 1)}
+                    ms.close()
+                    del d_ms, fv, cv, exp_m
+                    torch.cuda.empty_cache()
+            except Exception as e:                       # an extra must never cost the bench line
+                extras["many_streams_unique_captures"] = {"error": repr(e)[:300]}
         out["extras"] = extras
         base = d_base.cpu().numpy()
         raw = base.tobytes()

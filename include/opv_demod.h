@@ -153,15 +153,17 @@ int opv_process(opv_ctx* ctx);
 int opv_sync(opv_ctx* ctx);
 /* Stream-to-wavefront mapping of the front-end kernel (no counterpart in the reference, which is one thread
  * per process): 1 = one wavefront per stream (lowest per-symbol latency; right while the GPU has idle SIMDs),
- * 4 = four streams per wavefront (fewest issued instructions per symbol; right when every SIMD has work),
- * 0 = automatic (4 from 2049 streams per context; measured cross-over on MI355X).
+ * 4 = four streams per wavefront (fewer issued instructions per symbol; right when every SIMD has work),
+ * 16 = sixteen streams per wavefront, one per DPP quad (fewest issued instructions per symbol and stream: 38 against 88 and 156;
+ *      right from ~8 000 streams per context, where 16 per wave still put a wave on every second SIMD),
+ * 0 = automatic (4 from 2049 streams per context, 16 from 8193; measured cross-overs on MI355X).
  * Comparison build only (make -C opv-cxx-demod_amd variants -> build/cmp/libopv_demod_hip.so; the product library answers
  * OPV_EINVAL): -1 = one wavefront per stream with the product + permlane-swap reductions (the default until the row-broadcast
  * reduction replaced it: 1041 against 880 cycles per symbol), -2 = TWO wavefronts per stream, one per feedback loop (exact,
  * 6 % slower than -1). Results do not depend on the mapping beyond the fp64 re-association level of the soft symbols (all
  * decisions identical; the tests run every mapping). */
 int opv_set_frontend(opv_ctx* ctx, int streams_per_wave);
-/* Name of the front-end kernel the LAST opv_process launched ("k_msk_frontend_rb", "..._rb_wg4", "k_msk_frontend_x4_wg4", ...;
+/* Name of the front-end kernel the LAST opv_process launched ("k_msk_frontend_rb", "..._rb_wg4", "k_msk_frontend_x4_wg4", "k_msk_frontend_x16_wg4", ...;
  * "" before the first round): what a profile or a bench line should be read against. No counterpart in the reference. */
 const char* opv_frontend_kernel(opv_ctx* ctx);
 /* Restores a stream (stream = -1: every stream) to its freshly-created state (keeps buffers). */

@@ -30,6 +30,9 @@ extern "C" __global__ void k_msk_frontend_rb(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_rb_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4_wg4(OpvStream*, OpvGlobalCfg, int);
+extern "C" __global__ void k_msk_frontend_x16(OpvStream*, OpvGlobalCfg, int);
+extern "C" __global__ void k_msk_frontend_x16_wg4(OpvStream*, OpvGlobalCfg, int);
+extern "C" __global__ void k_msk_frontend_x16_wg8(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_coherent_frontend(OpvStream*, double, double);
 extern "C" __global__ void k_sync_track(OpvStream*);
 extern "C" __global__ void k_frame_scale(OpvStream*, uint32_t, uint32_t);
@@ -66,6 +69,9 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 // double up on SIMDs (k_frontend.hip: msk_frontend_body)
 constexpr int kFrontendWg4MinStreams = 512;
 constexpr int kFrontendX4Wg4MaxStreams = 8192;   // 2048 waves = two 80 KB workgroups per CU; beyond that single-wave workgroups (20 KB)
+constexpr int kFrontendX16MinStreams = 8192;      // measured on MI355X: 8192 streams x 16 frames: four per wave 260 GS/s, sixteen per wave 247 (512 waves: half the SIMDs idle);
+                                                  // 16 384 x 8: 187 / 478; 32 768 x 8: 204 / 574
+constexpr int kFrontendX16Wg8MinStreams = 16384;  // 1024 waves of sixteen streams = one per SIMD; beyond that eight waves (two per SIMD) per workgroup
 constexpr int kFrontendX4MinStreams = 2049;      // measured on MI355X: one wave per stream runs 1024 streams at a time (46 ms per 2048 x 30 frames, 69 ms from 2049 on), four per wave 4096 (47.5 ms)
 
 struct StreamIn {  // host -> device per-round update
@@ -551,6 +557,11 @@ extern "C" int opv_process(opv_ctx* c) {
         else { c->last_frontend = "k_msk_frontend"; k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g, S); }
     }
 #endif
+    else if (c->frontend == 16 || (c->frontend == 0 && S > kFrontendX16MinStreams)) {   // sixteen streams per wave (k_frontend_x16.hip): four waves (64 streams) per workgroup
+        if (S > kFrontendX16Wg8MinStreams) { c->last_frontend = "k_msk_frontend_x16_wg8"; k_msk_frontend_x16_wg8<<<(S + 127) / 128, 512, 0, c->stream>>>(c->d_streams, g, S); }
+        else if (S > 16) { c->last_frontend = "k_msk_frontend_x16_wg4"; k_msk_frontend_x16_wg4<<<(S + 63) / 64, 256, 0, c->stream>>>(c->d_streams, g, S); }
+        else { c->last_frontend = "k_msk_frontend_x16"; k_msk_frontend_x16<<<1, 64, 0, c->stream>>>(c->d_streams, g, S); }
+    }
     else if (x4 && S <= kFrontendX4Wg4MaxStreams) {      // up to two waves per SIMD: four waves (16 streams) per workgroup
         c->last_frontend = "k_msk_frontend_x4_wg4";
         k_msk_frontend_x4_wg4<<<(S + 15) / 16, 256, 0, c->stream>>>(c->d_streams, g, S);
@@ -593,8 +604,8 @@ extern "C" int opv_set_frontend(opv_ctx* c, int streams_per_wave) {
     if (streams_per_wave == -1 || streams_per_wave == -2)
         return fail(OPV_EINVAL, "opv_set_frontend: the comparison mappings (-1, -2) are not part of this build (make variants)");
 #endif
-    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4 && !cmp_ok)
-        return fail(OPV_EINVAL, "opv_set_frontend: 0 (automatic), 1 or 4 streams per wave");
+    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4 && streams_per_wave != 16 && !cmp_ok)
+        return fail(OPV_EINVAL, "opv_set_frontend: 0 (automatic), 1, 4 or 16 streams per wave");
     c->frontend = streams_per_wave;
     return OPV_OK;
 }

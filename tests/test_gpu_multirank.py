@@ -258,9 +258,10 @@ def test_512_stream_context_vs_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("S", [522, 2060])
+@pytest.mark.parametrize("S", [522, 2060, 8200])
 def test_many_stream_contexts_on_the_automatic_mapping(S):
-    """522 streams: one wave per stream, FOUR waves per workgroup (k_msk_frontend_rb_wg4, from 513 streams; 130 full
+    """8200 streams: beyond 8192 the shim takes sixteen streams per wave by itself (k_msk_frontend_x16_wg4: 128 full workgroups
+    of 64 streams + one with 8, i.e. a wave with eight idle quads and three waves that have nothing to do). 522 streams: one wave per stream, FOUR waves per workgroup (k_msk_frontend_rb_wg4, from 513 streams; 130 full
     workgroups + a partly filled one). 2060 streams: more than the one-wave-per-stream kernel holds in two rounds, the
     shim takes the four-per-wave mapping by itself (from 2049 streams; 128 full workgroups + a partly filled one, and
     the last wave has idle rows). 24 distinct captures (16 dB, different offsets / payloads) shared by the streams,
@@ -278,6 +279,7 @@ def test_many_stream_contexts_on_the_automatic_mapping(S):
         dm.attach(k, d_iq[k % D].data_ptr(), n, eof=True)
     dm.process()
     dm.sync()
+    assert dm.frontend_kernel() == {522: "k_msk_frontend_rb_wg4", 2060: "k_msk_frontend_x4_wg4", 8200: "k_msk_frontend_x16_wg4"}[S] or os.environ.get("OPV_FRONTEND")
     host = d_iq.cpu().numpy()
     o = Oracle()
     exp = [o.receive(host[j], streaming=True, want_soft=False) for j in range(D)]
