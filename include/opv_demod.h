@@ -20,7 +20,10 @@
 extern "C" {
 #endif
 
-#define OPV_ABI_VERSION 4   /* 4: + opv_tx_stream_* (the host modulator with its state carried from call to call), opv_tap_tx_frame;
+#define OPV_ABI_VERSION 5   /* 5: opv_set_frontend takes 16 (sixteen streams per wavefront; automatic from 8193 streams) and answers OPV_EINVAL to
+                               the comparison mappings -1 / -2 unless built with them; opv_create refuses non-finite -o / -a / -p values;
+                               an idle opv_process launches nothing for callers that never pop (zero-copy path);
+                               4: + opv_tx_stream_* (the host modulator with its state carried from call to call), opv_tap_tx_frame;
                                3: + opv_frontend_kernel, opv_tx_bert_frames, opv_tx_modulate_device_to_host, opv_tap_tx_checkpoints,
                                opv_comm_* / opv_gather_frames(_all); opv_tx_modulate_device runs the whole chain on the device;
                                an opv_process with nothing new still resumes streams held back by back-pressure */

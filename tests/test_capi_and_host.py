@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(amd):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/opv_demod.h but not exported"
     assert sorted(amd.EXPORTS) == names, "opv_amd.EXPORTS out of sync with the header"
-    assert L.opv_abi_version() == 4
+    assert L.opv_abi_version() == 5
 
 
 def test_struct_layouts_match_header(amd, tmp_path):
