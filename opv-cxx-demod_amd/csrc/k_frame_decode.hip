@@ -1,6 +1,6 @@
 // k_frame_decode.hip — scale -> 3-bit quantise -> 67x32 deinterleave -> soft-decision K=7 r=1/2
-// Viterbi (64 states) -> bit-pack -> CCSDS derandomise. One wavefront per frame: lane s owns
-// trellis state s.
+// Viterbi (64 states) -> bit-pack -> CCSDS derandomise. One wavefront per TWO frames: a lane owns one
+// trellis state of each (packed 16-bit path metrics).
 //
 // Replaces FrameDecoder::decode (reference src/opv-demod.cpp:854-898), deinterleave_addr
 // (:792-795) and ViterbiDecoder::decode (:800-847).

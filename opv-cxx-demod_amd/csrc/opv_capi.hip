@@ -585,7 +585,7 @@ extern "C" int opv_process(opv_ctx* c) {
     uint64_t fr = max_new / (uint64_t)(OPV_FSYMS * 38) + 4;
     if (fr > c->cap_frames) fr = c->cap_frames;
     if (fr * (uint64_t)S > 0x7FFFFFFFull) return fail(OPV_EINVAL, "opv_process: streams x frames per round exceeds the grid limit");
-    // the quantiser's scale (2144 dependent additions per frame) with one frame per lane, then one wave per frame
+    // the quantiser's scale (2144 dependent additions per frame) with one frame per lane, then one wave per two frames
     k_frame_scale<<<(unsigned)((fr * (uint64_t)S + 63) / 64), 64, 0, c->stream>>>(c->d_streams, (uint32_t)fr, (uint32_t)S);
     k_frame_decode<<<(unsigned)(((fr + 1) / 2) * (uint64_t)S), 64, 0, c->stream>>>(c->d_streams, (uint32_t)((fr + 1) / 2));   // two frames per wave
     if (tm) { HIPCHK(hipEventRecord(c->ev[7], c->stream)); c->timing_valid = true; }
