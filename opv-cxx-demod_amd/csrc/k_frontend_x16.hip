@@ -300,9 +300,11 @@ __device__ __forceinline__ void msk_frontend_x16_body(OpvStream* __restrict__ st
         double g0A = 0, g0B = 0, g0C = 0, g0D = 0, g1A = 0, g1B = 0, g1C = 0, g1D = 0, g2A = 0, g2B = 0, g2C = 0, g2D = 0;
         double x40c_l = 0.0, x40s_l = 0.0;
         double pr = (double)(int)(short)(w[0] & 0xFFFF), pi_ = (double)(w[0] >> 16);   // ref :1023
+        asm("" : "+v"(pr), "+v"(pi_));
 #pragma unroll
         for (int q = 0; q < 15; ++q) {
-            const double nr = (double)(int)(short)(w[q + 1] & 0xFFFF), ni = (double)(w[q + 1] >> 16);
+            double nr = (double)(int)(short)(w[q + 1] & 0xFFFF), ni = (double)(w[q + 1] >> 16);
+            asm("" : "+v"(nr), "+v"(ni));                          // (opaque: hipcc otherwise subtracts the int16 values and widens the difference too - 60 conversions instead of 32)
             double lr = fma(f, nr - pr, pr);                       // (differences of int16 values are exact in fp64)
             double li = fma(f, ni - pi_, pi_);
             if (kGeneric && first && pf + (double)q < 0.0) {        // early gate before the chunk: s[0] (ref :237)
