@@ -299,7 +299,9 @@ __device__ __forceinline__ void decode_two(const FrameIo& A, const FrameIo& B, u
                 auto q = __builtin_amdgcn_permlane16_swap(ptr, ptr, false, false); px = q[0]; py = q[1];
             } else {
                 auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false); x = r[0]; y = r[1];
-                auto q = __builtin_amdgcn_permlane32_swap(ptr, ptr, false, false); px = q[0]; py = q[1];
+                // K = 5 is the FIRST step of a group: every pointer is still its lane's own number, so the swapped pair would be
+                // (lane & 31, lane | 32) on both sides - no move needed, the select below is done on constants
+                px = kIdent & 0x001F001Fu; py = kIdent | 0x00200020u;
             }
             bsub = 0x00010001u;
         }
@@ -318,7 +320,7 @@ __device__ __forceinline__ void decode_two(const FrameIo& A, const FrameIo& B, u
             fldA[W] |= pa << SH;
             fldB[W] |= pb << SH;
             if constexpr (SH > 26) { fldA[W + 1] |= pa >> (32 - SH); fldB[W + 1] |= pb >> (32 - SH); }
-            ptr = kIdent;
+            // (no reset: the next step is a K = 5 step, which starts the pointers afresh by itself)
         }
     };
 #define OPV_ACS6(G, E, O)                                                                                                          \
