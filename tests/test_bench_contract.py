@@ -59,7 +59,7 @@ def _world2_env():
     return env
 
 
-def _check_world2_line(p, how):
+def _check_world2_line(p, how, world=2):
     out = ROOT / "gpurun_out"
     out.mkdir(exist_ok=True)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -70,20 +70,21 @@ def _check_world2_line(p, how):
     assert len(lines) == 1, p.stdout[-2000:]          # ONE line, from rank 0 only
     line = json.loads(lines[0])
     S, F = 8, 12
-    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    W = world
+    assert line["n_gpus"] == W and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
     c = line["collective"]
-    assert c["backend"] == "gloo" and c["world"] == 2
-    assert c["gathered_shape"][0] == 2 and c["gathered_shape"][1] == S and c["gathered_shape"][3] == 134
-    # rank 1 owns the global streams 8..15 - not a second copy of 0..7: said by the ranks, and read back from the bytes
-    assert c["rank_shards"] == [[0, S], [S, 2 * S]]
-    assert c["gathered_callsigns"] == [f"S{g}" for g in range(2 * S)]
-    assert c["rank_frames_released"] == [S * F, S * F]
+    assert c["backend"] == "gloo" and c["world"] == W
+    assert c["gathered_shape"][0] == W and c["gathered_shape"][1] == S and c["gathered_shape"][3] == 134
+    # rank r owns the global streams 8 r .. 8 r + 7 - not a second copy of 0..7: said by the ranks, and read back from the bytes
+    assert c["rank_shards"] == [[r * S, (r + 1) * S] for r in range(W)]
+    assert c["gathered_callsigns"] == [f"S{g}" for g in range(W * S)]
+    assert c["rank_frames_released"] == [S * F] * W
     chk = line["check"]
-    assert chk["gathered_frames_total"] == 2 * S * F
-    assert chk["gathered_frames_exact"] >= 2 * S * F - 2          # 16 dB: at most a stray channel error
+    assert chk["gathered_frames_total"] == W * S * F
+    assert chk["gathered_frames_exact"] >= W * S * F - W          # 16 dB: at most a stray channel error per rank
     assert chk["gathered_equals_local_view"] is True and chk["edge_ties"] == 0
-    # whole-job value: the samples of BOTH ranks over the max-over-ranks time
-    n = line["config"]["samples_per_stream"] * S * 2
+    # whole-job value: the samples of ALL ranks over the max-over-ranks time
+    n = line["config"]["samples_per_stream"] * S * W
     assert abs(line["value"] - n / (line["ms_per_step"] * 1e-3) / 1e6) < 0.01 * line["value"]
     r = line["roofline"]
     assert r["bound"] == "hbm" and r["kernel"].startswith("k_msk_frontend") and r["achieved"] > 0
@@ -102,17 +103,19 @@ def test_bench_world2_started_from_a_bare_shell():
 
 
 @pytest.mark.gpu
-def test_bench_world2_under_the_drivers_launcher():
-    """the driver's own command for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2
-    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher)"""
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_world2_under_the_drivers_launcher(world):
+    """the driver's own command for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher), with two and with four ranks on the one GPU"""
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    launch = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-              "--master-port", str(port), str(ROOT / "bench.py")] + WORLD2_ARGS
+    args = ["--gpus", str(world)] + WORLD2_ARGS[2:]
+    launch = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+              "--master-port", str(port), str(ROOT / "bench.py")] + args
     p = subprocess.run([sys.executable] + launch, env=_world2_env(), capture_output=True, text=True, timeout=420)
-    _check_world2_line(p, "python " + " ".join(launch[:-len(WORLD2_ARGS) - 1]) + " bench.py " + " ".join(WORLD2_ARGS))
+    _check_world2_line(p, "python " + " ".join(launch[:-len(args) - 1]) + " bench.py " + " ".join(args), world=world)
 
 
 @pytest.mark.gpu
