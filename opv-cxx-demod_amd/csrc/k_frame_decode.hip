@@ -464,6 +464,32 @@ extern "C" __global__ __launch_bounds__(64) void k_frame_scale(OpvStream* __rest
     }
 }
 
+// The same pre-pass for SMALL rounds (a live round of one frame per stream): one WAVE per frame. With one frame per lane a
+// round of 64 frames is a single wave whose lanes walk 64 different payloads - 46 us of memory latency for 2144 additions.
+// Here the wave fetches its frame's 17 KB at once (34 coalesced 512-byte loads, all in flight) into LDS and then adds the
+// 2144 values from there, in index order like the reference (:856-858; every lane runs the same chain, lane 0 stores).
+extern "C" __global__ __launch_bounds__(64) void k_frame_scale_wave(OpvStream* __restrict__ streams, uint32_t per_stream) {
+    __shared__ __attribute__((aligned(16))) double vals[OPV_CODED];
+    OpvStream& st = streams[blockIdx.x / per_stream];
+    const uint32_t n_frames = st.n_frames, mask = (uint32_t)(st.cap_soft - 1);
+    const int lane = threadIdx.x;
+    for (uint32_t f = st.dec_from + blockIdx.x % per_stream; f < n_frames; f += per_stream) {
+        const uint32_t slot = f % st.cap_frames, first = (uint32_t)st.frec[slot].payload_sym;
+        constexpr int kIter = (OPV_CODED + 63) / 64;            // 34 (the last one for lanes < 32 only)
+        double v[kIter];
+#pragma unroll
+        for (int k = 0; k < kIter; ++k) { const int i = lane + 64 * k; v[k] = st.soft[(first + (uint32_t)(i < OPV_CODED ? i : 0)) & mask]; }
+#pragma unroll
+        for (int k = 0; k < kIter; ++k) { const int i = lane + 64 * k; if (i < OPV_CODED) vals[i] = fabs(v[k]); }
+        __syncthreads();
+        double sum = 0.0;
+#pragma unroll 16
+        for (int i = 0; i < OPV_CODED; ++i) sum += vals[i];     // strictly in index order
+        if (lane == 0) st.fscale[slot] = sum / (double)OPV_CODED;
+        __syncthreads();                                         // the next frame reuses the buffer
+    }
+}
+
 // grid = n_streams x ceil(max new frames per stream / 2), flattened (stream-major: a stream's frames are neighbours, so are
 // their soft symbols in L2); a workgroup decodes frames dec_from + 2 j and dec_from + 2 j + 1 of its stream, then strides on
 extern "C" __global__ __launch_bounds__(64) void k_frame_decode(OpvStream* __restrict__ streams, uint32_t pairs_per_stream) {

@@ -36,6 +36,7 @@ extern "C" __global__ void k_msk_frontend_x16_wg8(OpvStream*, OpvGlobalCfg, int)
 extern "C" __global__ void k_coherent_frontend(OpvStream*, double, double);
 extern "C" __global__ void k_sync_track(OpvStream*);
 extern "C" __global__ void k_frame_scale(OpvStream*, uint32_t, uint32_t);
+extern "C" __global__ void k_frame_scale_wave(OpvStream*, uint32_t);
 extern "C" __global__ void k_frame_decode(OpvStream*, uint32_t);
 extern "C" __global__ void k_payload_scale(const double*, uint32_t, double*);
 extern "C" __global__ void k_decode_payloads(const double*, uint32_t, const double*, uint8_t*, int32_t*, int8_t*, int8_t*, uint8_t*);
@@ -67,6 +68,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 
 // one wave per stream, four of them per workgroup: from the stream count at which single-wave workgroups start to
 // double up on SIMDs (k_frontend.hip: msk_frontend_body)
+constexpr uint64_t kScaleWaveMaxFrames = 4096;    // frames (upper estimate) per round up to which the scale pre-pass runs one wave per frame
 constexpr int kFrontendWg4MinStreams = 512;
 constexpr int kFrontendX4Wg4MaxStreams = 8192;   // 2048 waves = two 80 KB workgroups per CU; beyond that single-wave workgroups (20 KB)
 constexpr int kFrontendX16MinStreams = 8192;      // measured on MI355X: 8192 streams x 16 frames: four per wave 260 GS/s, sixteen per wave 247 (512 waves: half the SIMDs idle);
@@ -586,7 +588,10 @@ extern "C" int opv_process(opv_ctx* c) {
     if (fr > c->cap_frames) fr = c->cap_frames;
     if (fr * (uint64_t)S > 0x7FFFFFFFull) return fail(OPV_EINVAL, "opv_process: streams x frames per round exceeds the grid limit");
     // the quantiser's scale (2144 dependent additions per frame) with one frame per lane, then one wave per two frames
-    k_frame_scale<<<(unsigned)((fr * (uint64_t)S + 63) / 64), 64, 0, c->stream>>>(c->d_streams, (uint32_t)fr, (uint32_t)S);
+    // (one frame per lane - the HBM-rate shape - for bulk rounds; one wave per frame while the round is so small that a wave of 64
+    // frames would be the whole launch: a live round of 64 frames 46 -> 12 us)
+    if (fr * (uint64_t)S <= kScaleWaveMaxFrames) k_frame_scale_wave<<<(unsigned)(fr * (uint64_t)S), 64, 0, c->stream>>>(c->d_streams, (uint32_t)fr);
+    else k_frame_scale<<<(unsigned)((fr * (uint64_t)S + 63) / 64), 64, 0, c->stream>>>(c->d_streams, (uint32_t)fr, (uint32_t)S);
     k_frame_decode<<<(unsigned)(((fr + 1) / 2) * (uint64_t)S), 64, 0, c->stream>>>(c->d_streams, (uint32_t)((fr + 1) / 2));   // two frames per wave
     if (tm) { HIPCHK(hipEventRecord(c->ev[7], c->stream)); c->timing_valid = true; }
     k_collect_counts<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_counts, S, c->h_stall + slot);
