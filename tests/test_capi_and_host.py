@@ -345,3 +345,13 @@ def test_product_library_carries_the_product_front_ends_only():
     kernels = sorted(ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("k_msk_frontend"))
     assert kernels == ["k_msk_frontend_rb", "k_msk_frontend_rb_wg4", "k_msk_frontend_x16", "k_msk_frontend_x16_wg4",
                        "k_msk_frontend_x16_wg8", "k_msk_frontend_x4", "k_msk_frontend_x4_wg4"], kernels
+
+
+def test_cli_refuses_non_finite_flag_values():
+    """`opv-demod -s -o inf`: the reference spins forever in its phase-wrap loops (src/opv-demod.cpp:255-262); here the value is
+    refused by opv_create before any device is touched - exit status 2 and a message, also on a box without a GPU."""
+    import subprocess
+    exe = str(ROOT / "opv-cxx-demod_amd" / "bin" / "opv-demod")
+    for flags in (["-s", "-o", "inf"], ["-s", "-a", "nan"], ["-c", "-p", "-inf"], ["-s", "-o", "1e999"]):
+        p = subprocess.run([exe, "-q"] + flags, input=b"\x00" * 4000, capture_output=True, timeout=30)
+        assert p.returncode == 2 and b"must be finite" in p.stderr, (flags, p.returncode, p.stderr)
