@@ -1,4 +1,4 @@
-"""one-off soak: EVERY stream of bench.py's workload (64 streams x 1000 frames, 16 dB, f0 -1500..+1500 Hz: BASELINE configs[3])
+"""one-off soak: EVERY stream of bench.py's workload (64 streams x 1000 frames, 16 dB, f0 -2000..+2000 Hz: BASELINE configs[3])
 through the HIP path in one context, and through the CPU oracle (8 worker processes, one stream at a time in host memory):
 frames, Viterbi metrics, sync positions, tracker events (kind / count / symbol), symbol count, offset estimate of every stream.
 tests/test_gpu_parity.py::test_config3_full_size_all_streams does the same in every suite run (round 4); this prints a line per stream."""

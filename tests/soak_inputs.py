@@ -75,11 +75,12 @@ def oracle_offset_chunk(caps):
     return [o.estimate_offset(c) for c in caps]
 
 
-def oracle_receive_job(x):
-    """one stream through the oracle's whole receive chain (-s semantics), without the soft log"""
+def oracle_receive_job(x, want_soft=False):
+    """one stream through the oracle's whole receive chain (-s semantics); the soft log (8 B per symbol) only on request"""
     from oracle_lib import Oracle
-    e = Oracle().receive(x, streaming=True, want_soft=False)
-    return {k: e[k] for k in ("frames", "metrics", "frame_sym", "events", "n_soft", "est_offset", "final_freq_offset")}
+    e = Oracle().receive(x, streaming=True, want_soft=want_soft)
+    keys = ("frames", "metrics", "frame_sym", "events", "n_soft", "est_offset", "final_freq_offset") + (("soft",) if want_soft else ())
+    return {k: e[k] for k in keys}
 
 
 def host_workers(cap=16):

@@ -85,7 +85,7 @@ def _rank_main(rank, world, port, per_rank, n_frames, ebn0, q):
 
 def test_world2_real_pipeline_every_global_stream_vs_oracle():
     """two processes, each opv_process on its contiguous shard of 8 streams (16 global streams x 12 frames,
-    16 dB, f0 -1500..-786 Hz), frames gathered to rank 0 by sharding.gather_frames"""
+    16 dB, f0 -2000..-1048 Hz), frames gathered to rank 0 by sharding.gather_frames"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

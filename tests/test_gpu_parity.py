@@ -1056,17 +1056,22 @@ def test_rx_bridge_udp_and_stdin_sources(amd, oracle, tmp_path):
 
 
 def test_config3_full_size_all_streams(amd):
-    """BASELINE configs[3] at full size, ALL 64 streams: bench.py's own workload (workload.generate: device modulator,
-    per-stream payload, f0 from -1500..+1500 Hz, 16 dB; 64 x 86 724 000 samples in HBM) through ONE opv_process, and every
-    stream against the oracle run on its own bytes (a process pool over the job's host cores, a wave of streams in host
-    memory at a time): frames, Viterbi metrics, release symbols, tracker events, symbol count, offset estimate, final AFC,
-    no one-tap windows (ref src/opv-demod.cpp:1012-1113)."""
+    """BASELINE configs[3] at full size, ALL 64 streams: bench.py's own workload - SURVEY.md §8(d) C4 as written
+    (workload.generate: device modulator, per-stream payload, f0 from -2000 to +2000 Hz across the 64 streams, 16 dB;
+    64 x 86 724 000 samples in HBM) - through ONE opv_process, and every stream against the oracle run on its own bytes (a
+    process pool over the job's host cores, a wave of streams in host memory at a time): frames, Viterbi metrics, release
+    symbols, tracker events, symbol count, offset estimate, final AFC, no one-tap windows (ref src/opv-demod.cpp:1012-1113).
+    The two edge streams (f0 = -/+2000 Hz: the AFC pinned at its clamp :303, the offset estimate saturating at the end of
+    its +/-1530 Hz span :135,169) and two interior ones also have ALL their ~2.17 M soft symbols compared (< 1e-9 of the
+    mean magnitude; contract 1e-5)."""
     import torch
     from concurrent.futures import ProcessPoolExecutor
     from __graft_entry__ import load_pkg_module
     from soak_inputs import host_workers, oracle_receive_job
     workload = load_pkg_module("workload")
     S, F = 64, 1000
+    SOFT_STREAMS = (0, 21, 42, 63)
+    assert [workload.stream_params(k, 16.0)[2] for k in (0, 63)] == [-2000.0, 2000.0]     # the recipe the bench line names
     dev = torch.device("cuda", 0)
     n = amd.lib().opv_tx_modulated_samples(F)
     d = amd.Demod(S, max_samples=n + 64, streaming=True)
@@ -1079,22 +1084,34 @@ def test_config3_full_size_all_streams(amd):
         assert d.frontend_kernel() == "k_msk_frontend_rb"        # the kernel the bench line's roofline is about
     W = host_workers()
     exact = total = 0
+    per_stream = {}
     with ProcessPoolExecutor(W) as pool:
         for k0 in range(0, S, W):
-            futs = {k: pool.submit(oracle_receive_job, d_iq[k].cpu().numpy()) for k in range(k0, min(S, k0 + W))}
+            futs = {k: pool.submit(oracle_receive_job, d_iq[k].cpu().numpy(), k in SOFT_STREAMS) for k in range(k0, min(S, k0 + W))}
             for k, fut in futs.items():
                 exp = fut.result()
                 fr, meta = d.pop_frames(k)
-                assert len(fr) == F and np.array_equal(fr, exp["frames"]), k
+                assert len(fr) == len(exp["frames"]) and np.array_equal(fr, exp["frames"]), k
                 assert np.array_equal(meta["viterbi_metric"], exp["metrics"]), k
                 assert np.array_equal(meta["release_symbol"], exp["frame_sym"]), k
                 events_match(amd, d.pop_events(k), exp["events"])
                 st = d.state(k)
                 assert st.total_symbols == exp["n_soft"] and st.est_offset_hz == exp["est_offset"], k
                 assert abs(st.freq_offset_hz - exp["final_freq_offset"]) < 1e-6, k
-                no_ties(st, f"configs[3] stream {k}")
-                exact += int((fr == tx[k]).all(axis=1).sum())
+                no_ties(st, f"configs[3] stream {k}", offset_ties=None)
+                if k in SOFT_STREAMS:
+                    a, r = soft_err(d.soft(k), exp["soft"])
+                    print(f"configs[3] stream {k} (f0 {workload.stream_params(k, 16.0)[2]:+.1f} Hz, estimate {st.est_offset_hz:+.1f}, "
+                          f"final AFC {st.freq_offset_hz:+.2f}): {len(exp['soft'])} soft symbols, max|d|/mean = {a:.2e}, max rel = {r:.2e}")
+                    assert a < SOFT_TIGHT and r < SOFT_RTOL, k
+                ok = int((fr[:F] == tx[k][: len(fr)]).all(axis=1).sum()) if len(fr) <= F else 0
+                per_stream[k] = (len(fr), ok, st.offset_ties)
+                exact += ok
                 total += len(fr)
+    worst = sorted(per_stream.items(), key=lambda kv: kv[1][1])[:4]
+    print("configs[3]: frames released", total, "equal to the transmitted ones", exact, "worst streams (released, exact, offset_ties)", worst)
+    assert sum(v[2] for v in per_stream.values()) <= 2            # (the near-tie guard: rare on ordinary captures, no_ties)
+    assert all(v[0] == F for v in per_stream.values()), {k: v for k, v in per_stream.items() if v[0] != F}
     assert total == S * F and exact >= 0.99 * total              # (the rest: channel errors at 16 dB, the same in the oracle)
     d.close()
 
