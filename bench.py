@@ -124,6 +124,50 @@ def cli_drop_in(iq_bytes, n_samples):
             "what": "bin/opv-demod -s -r -q (one stream = one wavefront) on the capture the reference binary was timed on, via a pipe"}
 
 
+def live_capacity(dev_index):
+    """The reference's real caller shape (`opv-modem -R`, src/opv-modem.cpp:673-838: IQ arrives at 2.168 MSPS, 40 ms per frame), for N
+    streams at once: how many live streams ONE context serves in real time. bin/opv-live-capacity (host/opv_live_capacity.cpp, a
+    C++ caller of the C ABI like opv-rx-bridge) runs 120 serving rounds - one 86 720-sample chunk per stream pushed from pinned host
+    memory over PCIe, opv_process, every stream's frames popped and compared - and reports the round-time distribution; the
+    capacity is the largest N probed whose p99 round stays under the 40 ms of signal a round consumes. Doubling, then bisection
+    to 256 streams."""
+    exe = ROOT / "opv-cxx-demod_amd" / "bin" / "opv-live-capacity"
+    if not exe.exists():
+        return None
+    probes = {}
+
+    def probe(n):
+        if n not in probes:
+            p = subprocess.run([str(exe), str(n), "120", "6", str(dev_index)], capture_output=True, text=True, timeout=180)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            probes[n] = json.loads(line[-1]) if p.returncode == 0 and line else {"streams": n, "error": (p.stderr or p.stdout)[-200:], "rc": p.returncode}
+        r = probes[n]
+        return "error" not in r and r["round_ms_p99"] < 40.0 and r["frames_wrong"] == 0
+    lo, hi = 0, None
+    n = 512
+    while n <= 8192:
+        if probe(n):
+            lo = n
+            n *= 2
+        else:
+            hi = n
+            break
+    while hi is not None and hi - lo > 256:
+        mid = (lo + hi) // 2 // 256 * 256
+        if mid <= lo or mid >= hi:
+            break
+        if probe(mid):
+            lo = mid
+        else:
+            hi = mid
+    best = probes.get(lo)
+    return {"streams": lo, "round_ms_p99": best["round_ms_p99"] if best else None, "round_ms_p50": best["round_ms_p50"] if best else None,
+            "Msamples/s_sustained": round(lo * 2.168, 1), "first_n_over_40ms": hi,
+            "probes": [probes[k] for k in sorted(probes)],
+            "what": "largest probed N with p99 round < 40 ms over 120 rounds: one 86720-sample chunk per stream from pinned host memory "
+                    "(opv_push_iq_batch), opv_process + opv_sync, opv_pop_frames of every stream (bin/opv-live-capacity)"}
+
+
 def cpu_all_cores(iq_bytes, n_samples):
     """The reference is single-threaded and streams are independent: one reference process per host core this
     job may use, each on its own copy of a bounded sample (200 frames) of the capture."""
@@ -687,6 +731,11 @@ def main():
                     torch.cuda.empty_cache()
             except Exception as e:                       # an extra must never cost the bench line
                 extras["many_streams_unique_captures"] = {"error": repr(e)[:300]}
+        if not args.no_big:
+            try:
+                extras["live_capacity"] = live_capacity(dev_index)
+            except Exception as e:                       # an extra must never cost the bench line
+                extras["live_capacity"] = {"error": repr(e)[:300]}
         out["extras"] = extras
         base = d_base.cpu().numpy()
         raw = base.tobytes()

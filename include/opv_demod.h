@@ -20,7 +20,9 @@
 extern "C" {
 #endif
 
-#define OPV_ABI_VERSION 5   /* 5: opv_set_frontend takes 16 (sixteen streams per wavefront; automatic from 8193 streams) and answers OPV_EINVAL to
+#define OPV_ABI_VERSION 6   /* 6: offset-search near-ties are decided with the HOST's libm (opv_offset_ties_on_host), one host wait in the round
+                               in which a stream's search runs;
+                               5: opv_set_frontend takes 16 (sixteen streams per wavefront; automatic from 8193 streams) and answers OPV_EINVAL to
                                the comparison mappings -1 / -2 unless built with them; opv_create refuses non-finite -o / -a / -p values;
                                an idle opv_process launches nothing for callers that never pop (zero-copy path);
                                4: + opv_tx_stream_* (the host modulator with its state carried from call to call), opv_tap_tx_frame;
@@ -116,7 +118,8 @@ typedef struct opv_stream_state {
     int32_t stalled;          /* back-pressure after the last opv_process: bit 0 = soft-symbol ring full, bit 1 = ring of
                                  unpopped frames full. The stream resumes at the next opv_process after opv_pop_frames */
     int32_t offset_ties;      /* offset-search candidates that were within 1e-11 (relative energy) of the winner and were
-                                 therefore re-evaluated in the reference's own order of operations (estimate_offset :143-159) */
+                                 therefore re-evaluated in the reference's own order of operations (estimate_offset :143-159) -
+                                 on the host, with the host's sin / cos (the reference's libm), when opv_offset_ties_on_host() is 1 */
 } opv_stream_state;
 
 typedef struct opv_ctx opv_ctx;
@@ -229,6 +232,12 @@ long opv_tap_soft(opv_ctx* ctx, int stream, uint64_t first_symbol, double* out, 
 long opv_tap_chunks(opv_ctx* ctx, int stream, uint32_t first_chunk, double* out5, size_t cap_chunks);
 /* 134 candidate energies of the offset search in scan order (121 coarse, 13 fine) */
 int opv_tap_offset_energies(opv_ctx* ctx, int stream, double* out134);
+/* Who decides the offset search's near-ties (estimate_offset's strict '>' between candidates whose energies differ in the last
+ * places of sin / cos, src/opv-demod.cpp:161,195): 1 = the host, with the contenders evaluated by the reference's own loop on the
+ * host's libm - opv_create found that this process's sin / cos reproduce a pinned reference energy (csrc/opv_offset_host.cpp);
+ * 0 = the device's sincos (another libm on the host, or OPV_OFFSET_DISTRUST_LIBM set): still the reference's order of
+ * operations, counted in offset_ties, but an exact tie is then decided by a different libm than the reference's. */
+int opv_offset_ties_on_host(opv_ctx* ctx);
 
 /* Where and how fast the wavefront that served `stream` ran in the LAST front-end launch (with four streams per
  * wave, the four share these numbers): out[0] = HW_REG_HW_ID, out[1] = HW_REG_XCC_ID, out[2] = shader-clock cycles (s_memtime) and

@@ -231,7 +231,10 @@ __device__ __noinline__ double2 silence_pd(double dr, double di, PrevSums prv, b
 
 }  // namespace
 
-#include "opv_atan2.h"  // kOpvAtanTab (constant-memory image of the table) + host reference routine
+#include "opv_atan2.h"  // kOpvAtanTabQ3R (constant-memory image of the angle table) + the host statement of the routine
+#ifdef OPV_WITH_COMPARISON_MAPPINGS
+#include "../variants/opv_atan2_cmp.h"   // kOpvAtanTab: the 33-row table of the round-1 body (comparison build only)
+#endif
 
 // ---- two-waves-per-stream mapping (ROLE 1 / 2 of msk_frontend_body): hand-over slots behind the atan table -------
 [[maybe_unused]] constexpr uint32_t kXchgPos = 0;      // 2 x {double pos; uint32 tag; pad}: position of symbol `tag`, written by the timing wave
@@ -526,7 +529,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         };
 
 #ifdef OPV_WITH_COMPARISON_MAPPINGS
-#include "k_frontend_cmp_symbol.inc"   // `symbol`: the round-1 body + the two-waves-per-stream statements (comparison build only)
+#include "../variants/k_frontend_cmp_symbol.inc"   // `symbol`: the round-1 body + the two-waves-per-stream statements (comparison build only)
 #endif
 
         // The same symbol with the ROW-BROADCAST reduction (RMAC; ROLE 0 only). gfx950's DP-ALU DPP form

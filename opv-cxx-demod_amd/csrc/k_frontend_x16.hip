@@ -1,7 +1,9 @@
 // k_frontend_x16.hip — MSK front-end for VERY MANY streams: SIXTEEN IQ streams per wavefront, one per DPP quad
 // (4 lanes), fifteen CONSECUTIVE interpolated samples per lane. Same arithmetic contract as k_frontend.hip /
 // k_frontend_x4.hip (reference src/opv-demod.cpp:206-329 + the chunker :1012-1113 / :1132-1173); selected with
-// opv_set_frontend(ctx, 16) (never automatically: DESIGN.md §3.1 has the measurement).
+// opv_set_frontend(ctx, 16), and by opv_process itself above 8192 streams per context (opv_capi.hip: kFrontendX16MinStreams;
+// bench.py's stream_sweep, front-end alone: 4096 x 15 frames 207 GS/s four-per-wave against 129 sixteen-per-wave - 256 waves
+// leave three SIMDs in four idle -, 8192 x 7: 221 against 255, 16 384 x 3: 175 against 407; see the constant's comment).
 //
 // Why: the per-stream arithmetic of a symbol is ~1080 lane-FMAs, everything else - loop filters,
 // divides, atan2, chunk bookkeeping - is scalar work per STREAM that a wave executes on all of its lanes. With four

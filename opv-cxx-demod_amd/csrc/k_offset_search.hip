@@ -28,6 +28,11 @@
 // the reference's order, windows summed in order; only libm's sin / cos are the device's), which shrinks
 // the undecidable band from 1e-13 to the last-place differences of sin / cos. The count of such
 // re-evaluations is reported (opv_stream_state.offset_ties).
+// That last band is closed on the HOST: a stream whose search re-evaluated anything puts its index on `tie_list` and
+// leaves its 19 polynomial coefficients in OpvStream.est_poly; opv_process (opv_capi.hip) then repeats the decision
+// for that stream with the contenders evaluated by opv_offset_candidate_energy (opv_offset_host.cpp) - the reference's
+// loop on the reference's own libm - before the front-end is launched. The device's own decision stands only when the
+// host's libm does not reproduce the pinned energy (tie_list == nullptr then).
 //
 // Roofline: 160 000 B read per stream, once. Compute: see above; no MFMA (the contraction is 40 x 40 per
 // window with weights that differ per tap - a GEMM only in name, and fp64).
@@ -96,8 +101,9 @@ __device__ double exact_energy(const int16_t* __restrict__ iq, int nsym, double 
 }  // namespace
 
 // wtab: [40 taps][2 (cos, sin)][kK] doubles = cos(pi i/80) u^k/k!, sin(pi i/80) u^k/k!, u = i - 19.5 (host-made, opv_create)
+// tie_list (device, may be null): [0] = number of streams that re-evaluated a candidate in this launch, [1 + i] = their indices
 extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
-                                                                   const double* __restrict__ wtab) {
+                                                                   const double* __restrict__ wtab, uint32_t* __restrict__ tie_list) {
     OpvStream& st = streams[blockIdx.x];
     if (st.first_chunk_done) return;
 
@@ -194,7 +200,7 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
     }
     if (tid == 0) { s_best_e = 0.0; s_best = 0.0; s_fine = 0.0; s_ties = 0; }
     __syncthreads();
-    if (tid < 2 * kK - 1) s_poly[tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+    if (tid < 2 * kK - 1) st.est_poly[tid] = s_poly[tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
     __syncthreads();
     auto poly_energy = [&](double offset) {
         const double th = kTwoPi * offset / kFs;
@@ -256,6 +262,8 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
         st.est_offset = s_fine;
         st.freq_offset = s_fine;  // demod.set_freq_offset(est) (ref :1033 / :1167)
         st.est_ties = (uint32_t)s_ties;
+        st.est_nsym = (uint32_t)nsym;
         st.first_chunk_done = 1;
+        if (s_ties > 0 && tie_list) tie_list[1 + atomicAdd(&tie_list[0], 1u)] = blockIdx.x;   // (capacity: one entry per stream)
     }
 }

@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <climits>
+#include <cstddef>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -18,9 +19,10 @@
 
 #include "../../include/opv_demod.h"
 #include "opv_device.h"
+#include "opv_offset_host.h"
 #include "opv_tx_internal.h"
 
-extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg, const double*);
+extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg, const double*, uint32_t*);
 #ifdef OPV_WITH_COMPARISON_MAPPINGS   // `make variants`: the round-1 body and the two-waves-per-stream mapping (opv_set_frontend -1 / -2)
 extern "C" __global__ void k_msk_frontend(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_wg4(OpvStream*, OpvGlobalCfg, int);
@@ -71,8 +73,8 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 constexpr uint64_t kScaleWaveMaxFrames = 4096;    // frames (upper estimate) per round up to which the scale pre-pass runs one wave per frame
 constexpr int kFrontendWg4MinStreams = 512;
 constexpr int kFrontendX4Wg4MaxStreams = 8192;   // 2048 waves = two 80 KB workgroups per CU; beyond that single-wave workgroups (20 KB)
-constexpr int kFrontendX16MinStreams = 8192;      // measured on MI355X: 8192 streams x 16 frames: four per wave 260 GS/s, sixteen per wave 247 (512 waves: half the SIMDs idle);
-                                                  // 16 384 x 8: 187 / 478; 32 768 x 8: 204 / 574
+constexpr int kFrontendX16MinStreams = 8192;      // measured on MI355X: 8192 streams x 16 frames: four per wave 260 GS/s, sixteen per wave 247 (512 waves: half the SIMDs idle;
+                                                  // with 7 frames per stream, bench.py's sweep, 221 / 255: the cross-over IS about 8192); 16 384 x 8: 187 / 478; 32 768 x 8: 204 / 574
 constexpr int kFrontendX16Wg8MinStreams = 16384;  // 1024 waves of sixteen streams = one per SIMD; beyond that eight waves (two per SIMD) per workgroup
 constexpr int kFrontendX4MinStreams = 2049;      // measured on MI355X: one wave per stream runs 1024 streams at a time (46 ms per 2048 x 30 frames, 69 ms from 2049 on), four per wave 4096 (47.5 ms)
 
@@ -120,6 +122,7 @@ struct HostStream {
     int eof = 0;
     bool dirty = false;
     bool attached = false;
+    bool search_seen = false;       // a round in which k_offset_search could run for this stream has been launched
     uint64_t last_round_avail = 0;
     uint32_t popped = 0;        // frame records already handed out
     uint32_t events_popped = 0;
@@ -157,6 +160,12 @@ struct opv_ctx {
     double* d_fscale = nullptr;
     int32_t* d_counts = nullptr;
     double* d_offs_wtab = nullptr;      // k_offset_search's moment weights: [40 taps][cos, sin][OPV_OFFS_TERMS]
+    // offset-search ties are decided with the HOST's libm (opv_offset_host.cpp): streams whose search re-evaluated a candidate
+    // put themselves on d_tie_list ([0] = count, then indices); opv_process reads it behind the search, before the front-end
+    uint32_t* d_tie_list = nullptr;
+    uint32_t* h_tie_list = nullptr;     // pinned, 1 + n_streams words
+    bool host_ties = false;             // the host's libm reproduces the pinned reference energy (probed at opv_create)
+    std::vector<int16_t> tie_iq;        // <= 40 000 samples of the stream being decided
     uint64_t cap_soft = 0;
     uint32_t cap_frames = 0, cap_events = 0, cap_chunks = 0;
     bool mirror_valid = false;
@@ -338,6 +347,11 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
         HIPCHK_C(hipMalloc(&c->d_offs_wtab, sizeof(double) * w.size()));
         HIPCHK_C(hipMemcpy(c->d_offs_wtab, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice));
     }
+    c->host_ties = opv_offset_host_libm_matches_reference() && !std::getenv("OPV_OFFSET_DISTRUST_LIBM");   // (test hook: the device-sincos path)
+    if (c->host_ties) {
+        HIPCHK_C(hipMalloc(&c->d_tie_list, sizeof(uint32_t) * (S + 1)));
+        HIPCHK_C(hipHostMalloc(&c->h_tie_list, sizeof(uint32_t) * (S + 1), hipHostMallocDefault));
+    }
     HIPCHK_C(hipMemsetAsync(c->d_frames, 0, (size_t)OPV_FB * c->cap_frames * S, c->stream));
     HIPCHK_C(hipMemsetAsync(c->d_counts, 0, sizeof(int32_t) * S, c->stream));
     k_fill_i32<<<256, 256, 0, c->stream>>>(c->d_metrics, INT32_MIN, (size_t)c->cap_frames * S);
@@ -382,6 +396,7 @@ extern "C" void opv_destroy(opv_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_stall) (void)hipHostFree(c->h_stall);
+    if (c->h_tie_list) (void)hipHostFree(c->h_tie_list);
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& h : c->hs) {
@@ -390,7 +405,7 @@ extern "C" void opv_destroy(opv_ctx* c) {
     }
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
-    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_fscale, c->d_counts, c->d_tx_phases, c->d_offs_wtab, c->d_tx_ckpt, c->d_tx_frames, c->d_tx_codes, c->d_tx_fpar, c->d_tx_cnt, c->d_tx_list, c->d_tx_flat};
+    void* ptrs[] = {c->d_streams, c->d_in, c->d_soft, c->d_frec, c->d_events, c->d_chunks, c->d_frames, c->d_metrics, c->d_fscale, c->d_counts, c->d_tx_phases, c->d_offs_wtab, c->d_tx_ckpt, c->d_tx_frames, c->d_tx_codes, c->d_tx_fpar, c->d_tx_cnt, c->d_tx_list, c->d_tx_flat, c->d_tie_list};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -503,6 +518,42 @@ extern "C" int opv_attach_device_iq(opv_ctx* c, int s, const int16_t* d_iq, size
     return OPV_OK;
 }
 
+// Streams whose offset search re-evaluated a candidate (k_offset_search.hip: tie_list): the decision is repeated here with the
+// contenders evaluated by the reference's loop on the host's libm, and the estimate, the energies tap and the tie count of
+// the stream are replaced before the front-end reads them. Waits for the search kernel.
+static int resolve_offset_ties(opv_ctx* c) {
+    const size_t S = (size_t)c->n_streams;
+    const size_t head = S + 1 < 64 ? S + 1 : 64;
+    HIPCHK(hipMemcpyAsync(c->h_tie_list, c->d_tie_list, sizeof(uint32_t) * head, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    size_t n = c->h_tie_list[0];
+    if (n == 0) return OPV_OK;
+    if (n > S) return fail(OPV_EHIP, "offset search: tie list overrun (internal)");
+    if (n + 1 > head) HIPCHK(hipMemcpy(c->h_tie_list + head, c->d_tie_list + head, sizeof(uint32_t) * (n + 1 - head), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t s = c->h_tie_list[1 + i];
+        if (s >= S) return fail(OPV_EHIP, "offset search: bad tie list entry (internal)");
+        OpvStream st;
+        HIPCHK(hipMemcpy(&st, c->d_streams + s, sizeof st, hipMemcpyDeviceToHost));
+        const size_t nsym = st.est_nsym;
+        if (nsym == 0 || nsym > 1000) return fail(OPV_EHIP, "offset search: bad window count (internal)");
+        c->tie_iq.resize(2 * (size_t)OPV_SPS * nsym);
+        HIPCHK(hipMemcpy(c->tie_iq.data(), st.iq, sizeof(int16_t) * c->tie_iq.size(), hipMemcpyDeviceToHost));
+        uint32_t ties = 0;
+        double energies[134];
+        const double est = opv_offset_decide_on_host(c->tie_iq.data(), nsym, st.est_poly, energies, &ties);
+        if (ties == 0) continue;                           // (the same polynomial gives the same contenders: not expected)
+        st.freq_offset = st.est_offset = est;              // demod.set_freq_offset(est) (ref :1033 / :1167)
+        st.est_ties = ties;
+        std::memcpy(st.energies, energies, sizeof energies);
+        char* d = (char*)(c->d_streams + s);
+        HIPCHK(hipMemcpy(d + offsetof(OpvStream, freq_offset), &st.freq_offset, sizeof(double), hipMemcpyHostToDevice));
+        const size_t a = offsetof(OpvStream, est_offset), b = offsetof(OpvStream, energies) + sizeof st.energies;
+        HIPCHK(hipMemcpy(d + a, (const char*)&st + a, b - a, hipMemcpyHostToDevice));
+    }
+    return OPV_OK;
+}
+
 extern "C" int opv_process(opv_ctx* c) {
     if (!c) return fail(OPV_EINVAL, "null context");
     HIPCHK(hipSetDevice(c->cfg.device));
@@ -511,11 +562,16 @@ extern "C" int opv_process(opv_ctx* c) {
     if (c->round_no >= (unsigned)opv_ctx::kInSlots) HIPCHK(hipEventSynchronize(c->in_ev[slot]));  // upload of round_no-kInSlots done
     StreamIn* in = c->h_in + (size_t)slot * S;
     uint64_t max_new = 0;
-    bool any = false;
+    bool any = false, may_search = false;
     for (int i = 0; i < S; ++i) {
         HostStream& h = c->hs[i];
         in[i] = {h.d_iq, h.n_avail, h.eof, h.dirty ? 1 : 0, h.popped, h.events_popped};
         if (h.dirty) any = true;
+        // k_offset_search's own condition (first full chunk in streaming mode, EOF in batch mode), once per stream
+        if (!h.search_seen && (c->cfg.streaming ? h.n_avail >= (uint64_t)OPV_CHUNK : h.eof != 0)) {
+            h.search_seen = true;
+            may_search |= !(c->cfg.streaming && c->cfg.have_init_offset);
+        }
         const uint64_t fresh = h.n_avail - h.last_round_avail;
         if (fresh > max_new) max_new = fresh;
         h.last_round_avail = h.n_avail;
@@ -528,6 +584,10 @@ extern "C" int opv_process(opv_ctx* c) {
     if (!any && c->maybe_stalled && c->round_no > 0 && hipEventQuery(c->done_ev) == hipSuccess)
         c->maybe_stalled = c->h_stall[(c->round_no - 1) % opv_ctx::kInSlots] != 0;
     if (!any && !c->maybe_stalled) return OPV_OK;
+    // frames a stream can release this round: new symbols / 2168 plus what was pending (checked before anything is launched)
+    uint64_t fr = max_new / (uint64_t)(OPV_FSYMS * 38) + 4;
+    if (fr > c->cap_frames) fr = c->cap_frames;
+    if (fr * (uint64_t)S > 0x7FFFFFFFull) return fail(OPV_EINVAL, "opv_process: streams x frames per round exceeds the grid limit");
     c->mirror_valid = false;
     c->maybe_stalled = true;
     c->h_stall[slot] = 0;          // (a straggler of round_no - kInSlots could still set it: then one idle round too many, never one too few)
@@ -539,8 +599,15 @@ extern "C" int opv_process(opv_ctx* c) {
     k_apply_inputs<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_in, S);
     const bool tm = c->timing;
     if (tm) HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    k_offset_search<<<S, 256, 0, c->stream>>>(c->d_streams, g, c->d_offs_wtab);
-    if (tm) { HIPCHK(hipEventRecord(c->ev[1], c->stream)); HIPCHK(hipEventRecord(c->ev[2], c->stream)); }
+    const bool host_ties = may_search && c->host_ties;
+    if (host_ties) HIPCHK(hipMemsetAsync(c->d_tie_list, 0, sizeof(uint32_t), c->stream));
+    k_offset_search<<<S, 256, 0, c->stream>>>(c->d_streams, g, c->d_offs_wtab, host_ties ? c->d_tie_list : nullptr);
+    if (tm) HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    // the one host wait of the path, in the round(s) in which a stream's offset search runs: near-ties are decided with the
+    // host's libm before the front-end takes the estimate (opv_offset_host.cpp)
+    if (host_ties)
+        if (int r = resolve_offset_ties(c)) return r;
+    if (tm) HIPCHK(hipEventRecord(c->ev[2], c->stream));
     // one wave per stream has the shortest per-symbol latency (what counts while SIMDs are idle); four streams per
     // wave issue fewer instructions per symbol and stream, which pays once there are more streams than the one-wave
     // kernel's two rounds of 1024 hold
@@ -583,10 +650,6 @@ extern "C" int opv_process(opv_ctx* c) {
     if (tm) { HIPCHK(hipEventRecord(c->ev[3], c->stream)); HIPCHK(hipEventRecord(c->ev[4], c->stream)); }
     k_sync_track<<<S, 64, 0, c->stream>>>(c->d_streams);
     if (tm) { HIPCHK(hipEventRecord(c->ev[5], c->stream)); HIPCHK(hipEventRecord(c->ev[6], c->stream)); }
-    // frames a stream can release this round: new symbols / 2168 plus what was pending
-    uint64_t fr = max_new / (uint64_t)(OPV_FSYMS * 38) + 4;
-    if (fr > c->cap_frames) fr = c->cap_frames;
-    if (fr * (uint64_t)S > 0x7FFFFFFFull) return fail(OPV_EINVAL, "opv_process: streams x frames per round exceeds the grid limit");
     // the quantiser's scale (2144 dependent additions per frame) with one frame per lane, then one wave per two frames
     // (one frame per lane - the HBM-rate shape - for bulk rounds; one wave per frame while the round is so small that a wave of 64
     // frames would be the whole launch: a live round of 64 frames 46 -> 12 us)
@@ -837,6 +900,8 @@ extern "C" int opv_tap_offset_energies(opv_ctx* c, int s, double* out134) {
     std::memcpy(out134, c->mirror[s].energies, sizeof(double) * 134);
     return OPV_OK;
 }
+
+extern "C" int opv_offset_ties_on_host(opv_ctx* c) { return c && c->host_ties ? 1 : 0; }
 
 extern "C" int opv_tap_wave_info(opv_ctx* c, int s, uint64_t out[4]) {
     if (int r = check_stream(c, s)) return r;

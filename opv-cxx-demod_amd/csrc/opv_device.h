@@ -66,8 +66,10 @@ struct OpvStream {
     double x40c, x40s;
     double fo_sum;            // sum of the freq_offset used by every symbol so far (absolute LO phase, see k_frontend)
     double est_offset;        // NaN until estimate_offset ran
-    uint32_t est_ties, pad2;  // offset-search candidates re-evaluated in the reference's order (near-ties)
+    uint32_t est_ties;        // offset-search candidates re-evaluated in the reference's order (near-ties)
+    uint32_t est_nsym;        // 40-sample windows the search used (min(N, 40 000) / 40, ref :141)
     double energies[134];     // offset-search tap
+    double est_poly[2 * OPV_OFFS_TERMS - 1];   // the search's energy polynomial in theta = 2 pi o / Fs (k_offset_search.hip), for the host's tie decision
 
     // ---- chunker carry (ref :1012-1076) ----
     uint64_t origin;          // sample index where the next demodulate() call starts

@@ -1,0 +1,117 @@
+// opv_offset_host.cpp — the carrier-offset search's TIE decision on the host.
+//
+// k_offset_search.hip evaluates the 134 candidates of MSKDemodulatorAFC::estimate_offset (reference
+// src/opv-demod.cpp:131-202) from ONE pass over the samples; its energies agree with the reference's to ~1e-13
+// relative. When another candidate lies within 1e-11 of the winner the order of the two is decided by the last places
+// of sin / cos - i.e. by libm. The reference's libm is the host's, not the device's: for such a stream opv_process
+// brings the first <= 40 000 samples (160 KB) back and repeats the decision here, the contenders evaluated by the
+// reference's own loop (phases accumulated sample by sample from zero, one sin and one cos per LO and sample, sums in
+// its order) with the host's sin / cos. Same pattern as the transmit chain's ambiguous samples (opv_capi.hip:
+// opv_tx_modulate_device). Compiled with the host compiler, -ffp-contract=off (Makefile: CXXFLAGS).
+//
+// This is product code: a few candidates of a few streams (the guard fires on <= 4 of 512 ordinary captures), never the
+// whole search and never the receive chain - there is no CPU implementation of the hot path in this library.
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+
+#include "opv_device.h"
+#include "opv_offset_host.h"
+
+namespace {
+constexpr double kTwoPi = 2.0 * 3.14159265358979323846;  // ref :43-44
+constexpr double kFs = 2168000.0;                        // ref :40
+constexpr double kFdev = 13550.0;                        // ref :42
+constexpr int kTerms = 2 * OPV_OFFS_TERMS - 1;
+constexpr double kTieRel = 1e-11;                        // k_offset_search.hip: kTieRel
+}  // namespace
+
+// ref :143-159 for one candidate: energy over nsym fixed 40-sample windows from sample 0
+double opv_offset_candidate_energy(const int16_t* iq, size_t nsym, double offset) {
+    const double inc1 = kTwoPi * (-kFdev + offset) / kFs;   // ref :137
+    const double inc2 = kTwoPi * (+kFdev + offset) / kFs;   // ref :138
+    double ph1 = 0.0, ph2 = 0.0, total = 0.0;
+    const int16_t* x = iq;
+    for (size_t s = 0; s < nsym; ++s) {
+        double c1r = 0.0, c1i = 0.0, c2r = 0.0, c2i = 0.0;
+        for (int i = 0; i < OPV_SPS; ++i, x += 2) {
+            const double re = (double)x[0], im = (double)x[1];
+            const double k1 = std::cos(ph1), s1 = std::sin(ph1);
+            const double k2 = std::cos(ph2), s2 = std::sin(ph2);
+            c1r += re * k1 + im * s1;                        // s * conj(lo) (ref :151-152)
+            c1i += im * k1 - re * s1;
+            c2r += re * k2 + im * s2;
+            c2i += im * k2 - re * s2;
+            ph1 += inc1;                                     // never wrapped (ref :154-155)
+            ph2 += inc2;
+        }
+        total += (c1r * c1r + c1i * c1i) + (c2r * c2r + c2i * c2i);   // ref :158
+    }
+    return total;
+}
+
+// The decision of k_offset_search.hip (`decide`, coarse then fine), candidate for candidate, with the contenders
+// re-evaluated by opv_offset_candidate_energy. poly: the device's 19 coefficients; the Horner evaluation below is the
+// device's own (fma, same operand order), so the polynomial energies and with them the set of contenders are the device's.
+double opv_offset_decide_on_host(const int16_t* iq, size_t nsym, const double* poly, double* energies134, uint32_t* ties_out) {
+    auto poly_energy = [&](double offset) {
+        const double th = kTwoPi * offset / kFs;
+        double e = poly[kTerms - 1];
+        for (int p = kTerms - 2; p >= 0; --p) e = std::fma(e, th, poly[p]);
+        return e;
+    };
+    double e[134];
+    double best_e = 0.0, best = 0.0, fine_best = 0.0;
+    uint32_t ties = 0;
+    auto decide = [&](int c0, int c1, double base, double step, bool fine) {
+        auto off = [&](int c) { return base + step * (double)(c - c0); };
+        for (int c = c0; c < c1; ++c) e[c] = poly_energy(off(c));
+        double top = best_e;
+        for (int c = c0; c < c1; ++c) top = std::fmax(top, e[c]);
+        if (top > 0.0) {
+            const double bar = top * (1.0 - kTieRel);
+            auto in_play = [&](int c) { return e[c] >= bar && !(fine && off(c) == best); };
+            int contenders = (fine && best_e >= bar) ? 1 : 0;
+            for (int c = c0; c < c1; ++c) contenders += in_play(c);
+            if (contenders > 1) {
+                const bool defend = fine && best_e >= bar;       // (decided before any energy is replaced, like the device's uniform flow)
+                for (int c = c0; c < c1; ++c)
+                    if (in_play(c)) { e[c] = opv_offset_candidate_energy(iq, nsym, off(c)); ++ties; }
+                if (defend) { best_e = opv_offset_candidate_energy(iq, nsym, best); ++ties; }
+            }
+        }
+        for (int c = c0; c < c1; ++c) {
+            energies134[c] = e[c];
+            if (fine && off(c) == best) continue;                 // the coarse winner's own repeat: never '>' in the reference
+            if (e[c] > best_e) {                                  // strict: first maximum wins (ref :161, :195)
+                best_e = e[c];
+                if (fine) fine_best = off(c);
+                else best = off(c);
+            }
+        }
+        if (!fine) fine_best = best;                              // ref :168
+    };
+    decide(0, 121, -1500.0, 25.0, false);                        // ref :135
+    decide(121, 134, best - 30.0, 5.0, true);                    // ref :169
+    *ties_out = ties;
+    return fine_best;
+}
+
+// Does THIS process's libm reproduce the energy the reference's evaluation gives (glibc 2.35, x86-64; the pinned value is
+// checked against the test suite's CPU restatement of estimate_offset, itself bit-identical to the compiled reference:
+// tests/test_capi_and_host.py)? 1000 windows of a fixed pseudo-random int16 sequence at +1425 Hz (a coarse candidate, so
+// that an energy table of the whole search holds the same number): phases run to ~1.6e3 rad, every quadrant and
+// range-reduction path the real evaluation takes. ~3 ms, once per process.
+bool opv_offset_host_libm_matches_reference() {
+    static const bool ok = [] {
+        static int16_t iq[2 * 40000];
+        uint32_t v = 0x2545F491u;
+        for (int k = 0; k < 2 * 40000; ++k) {
+            v = v * 1664525u + 1013904223u;
+            iq[k] = (int16_t)((int32_t)(v >> 16) % 4001 - 2000);
+        }
+        const double e = opv_offset_candidate_energy(iq, 1000, OPV_OFFSET_PROBE_HZ);
+        return e == OPV_OFFSET_PROBE_ENERGY;
+    }();
+    return ok;
+}

@@ -254,13 +254,14 @@ int main(int argc, char** argv) {
             fprintf(stderr, "  -q          Quiet mode\n");
             fprintf(stderr, "  -r          Raw output to stdout\n");
             fprintf(stderr, "  -s          Streaming mode (for live PlutoSDR input)\n");
-            fprintf(stderr, "  -c          Coherent mode (Costas loop, ~3dB better; batch mode only)\n");
+            fprintf(stderr, "  -c          Coherent mode (Costas loop, ~3dB better)\n");
             fprintf(stderr, "  -a <bw>     AFC bandwidth (default: 0.001)\n");
             fprintf(stderr, "  -o <hz>     Initial frequency offset (streaming mode)\n");
-            fprintf(stderr, "  -p <hz>     PLL bandwidth for coherent mode (default: 50)\n");
+            fprintf(stderr, "  -p <hz>     PLL bandwidth in Hz (default: 50, coherent only)\n");
+            fprintf(stderr, "  -h          Help\n");
+            // the reference's text ends here (ref :962-971, byte for byte above); two flags it does not have follow
             fprintf(stderr, "  --device <n>        HIP device ordinal (default 0)\n");
             fprintf(stderr, "  --capacity-sec <s>  device staging buffer in seconds of IQ (default 2; streams may be any length)\n");
-            fprintf(stderr, "  -h          Help\n");
             return 0;
         }
     }
@@ -380,10 +381,13 @@ int main(int argc, char** argv) {
     if (st.stalled) {
         sink.err = open_memstream(&held, &held_n);
         if (!sink.err) return die("open_memstream");
-        if (sink.drain() < 0) return die("drain");
-        if (finish(ctx, sink) < 0) return die("finish");
-        fclose(sink.err);
+        const bool ok = sink.drain() >= 0 && finish(ctx, sink) >= 0;
+        fclose(sink.err);                  // (completes `held`)
         sink.err = stderr;
+        if (!ok) {                         // what was decoded before the failure is not lost with it
+            if (held) { fwrite(held, 1, held_n, stderr); free(held); }
+            return die("drain / finish");
+        }
         if (opv_get_state(ctx, 0, &st) < 0) return die("opv_get_state");
     }
     if (!o.quiet) {

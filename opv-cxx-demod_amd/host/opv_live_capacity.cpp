@@ -1,0 +1,112 @@
+// opv_live_capacity.cpp — how many LIVE streams one GPU context serves in real time, measured the way the boundary's real caller
+// uses it (reference `opv-modem -R`, src/opv-modem.cpp:673-838: IQ arrives at 2.168 MSPS, one frame = 86 720 samples = 40 ms).
+//
+// A serving round is what opv-rx-bridge does for every 40 ms of signal, for N streams at once: one 86 720-sample chunk per
+// stream pushed from (pinned) host memory across PCIe (opv_push_iq_batch), one opv_process, every stream's frames popped
+// (opv_pop_frames). The context keeps up with real time while a round takes less than the 40 ms of signal it consumes. This
+// tool runs R rounds for a given N and prints the distribution of the round time as one JSON line; bench.py searches for the
+// largest N whose p99 stays under 40 ms (extras.live_capacity). No kernel is specific to this tool: it is a caller of
+// include/opv_demod.h like opv-rx-bridge, without sockets so that the number is the library's.
+//
+//   opv-live-capacity <n_streams> [rounds (120)] [warmup (6)] [device (0)]
+//
+// Every stream carries the same clean BERT capture (host modulator, bit-identical to `opv-mod -S W5NYV -B <rounds + warmup + 1>`);
+// the N copies still cross PCIe separately and are demodulated separately. Checked: after the first round every round releases
+// exactly one frame per stream, equal to the transmitted one.
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>   // pinned host memory for the chunks (what a DMA-fed SDR server would hold them in)
+
+#include "../../include/opv_demod.h"
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        fprintf(stderr, "Usage: %s <n_streams> [rounds] [warmup] [device]\n", argv[0]);
+        return 2;
+    }
+    const int N = atoi(argv[1]);
+    const int rounds = argc > 2 ? atoi(argv[2]) : 120, warm = argc > 3 ? atoi(argv[3]) : 6, device = argc > 4 ? atoi(argv[4]) : 0;
+    if (N < 1 || rounds < 1 || warm < 1) { fprintf(stderr, "opv-live-capacity: bad arguments\n"); return 2; }
+    const int total = rounds + warm;
+    const size_t chunk = OPV_CHUNK_SAMPLES;
+
+    // the signal: total + 1 frames (+ the modulator's 100 silent symbols), in pinned memory
+    std::vector<uint8_t> frames((size_t)(total + 1) * OPV_FRAME_BYTES);
+    opv_tx_bert_frames("W5NYV", 0xBBAADD, 0, (size_t)total + 1, frames.data());
+    const size_t n_all = opv_tx_modulated_samples((size_t)total + 1);
+    int16_t* iq = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipHostMalloc((void**)&iq, n_all * 4, hipHostMallocDefault) != hipSuccess) {
+        fprintf(stderr, "opv-live-capacity: no pinned host memory / no HIP device\n");
+        return 2;
+    }
+    opv_tx_modulate(frames.data(), (size_t)total + 1, iq);
+
+    opv_cfg cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.streaming = 1;
+    cfg.afc_alpha = 0.001;
+    cfg.device = device;
+    cfg.pll_bw_hz = 50.0;
+    cfg.max_samples = 4 * chunk + 65536;               // a live server's staging buffer: a few chunks per stream
+    opv_ctx* ctx = nullptr;
+    if (opv_create(&ctx, N, &cfg) < 0) { fprintf(stderr, "opv-live-capacity: %s\n", opv_last_error()); return 2; }
+
+    std::vector<int> ids(N);
+    std::vector<const int16_t*> ptrs(N);
+    std::vector<size_t> lens(N, chunk);
+    for (int k = 0; k < N; ++k) ids[k] = k;
+    std::vector<double> t_round, t_push, t_proc, t_pop;
+    uint8_t out[4 * OPV_FRAME_BYTES];
+    opv_frame_meta meta[4];
+    long released = 0, wrong = 0, imperfect = 0, uneven = 0;
+    std::vector<size_t> next(N, 0);                     // per stream: the number of the next frame it owes
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    for (int r = 0; r < total; ++r) {
+        for (int k = 0; k < N; ++k) ptrs[k] = iq + 2 * (size_t)r * chunk;
+        const auto t0 = clk::now();
+        if (opv_push_iq_batch(ctx, N, ids.data(), ptrs.data(), lens.data()) < 0) { fprintf(stderr, "push: %s\n", opv_last_error()); return 2; }
+        const auto t1 = clk::now();
+        if (opv_process(ctx) < 0 || opv_sync(ctx) < 0) { fprintf(stderr, "process: %s\n", opv_last_error()); return 2; }
+        const auto t2 = clk::now();
+        long got_round = 0;
+        for (int k = 0; k < N; ++k) {
+            const long g = opv_pop_frames(ctx, k, out, 4, meta);
+            if (g < 0) { fprintf(stderr, "pop: %s\n", opv_last_error()); return 2; }
+            for (long f = 0; f < g; ++f) {
+                const size_t idx = next[k]++;
+                if (idx > (size_t)total || memcmp(out + f * OPV_FRAME_BYTES, frames.data() + idx * OPV_FRAME_BYTES, OPV_FRAME_BYTES) != 0) ++wrong;
+                if (meta[f].viterbi_metric != 0) ++imperfect;
+            }
+            got_round += g;
+        }
+        const auto t3 = clk::now();
+        if (r >= 1 && got_round != N) ++uneven;         // (one frame per stream and round once the first chunk is in: the steady state)
+        released += got_round;
+        if (r >= warm) {
+            t_round.push_back(ms(t0, t3));
+            t_push.push_back(ms(t0, t1));
+            t_proc.push_back(ms(t1, t2));
+            t_pop.push_back(ms(t2, t3));
+        }
+    }
+    auto pct = [](std::vector<double> v, double p) {
+        std::sort(v.begin(), v.end());
+        const size_t i = (size_t)(p * (double)(v.size() - 1) + 0.5);
+        return v[i < v.size() ? i : v.size() - 1];
+    };
+    printf("{\"streams\": %d, \"rounds\": %d, \"signal_ms_per_round\": 40.0, \"round_ms_p50\": %.3f, \"round_ms_p99\": %.3f, \"round_ms_max\": %.3f, "
+           "\"push_ms_p50\": %.3f, \"process_ms_p50\": %.3f, \"pop_ms_p50\": %.3f, \"pcie_GBps_p50\": %.2f, \"frames_released\": %ld, "
+           "\"frames_wrong\": %ld, \"frames_imperfect\": %ld, \"rounds_not_one_frame_per_stream\": %ld}\n",
+           N, rounds, pct(t_round, 0.5), pct(t_round, 0.99), pct(t_round, 1.0), pct(t_push, 0.5), pct(t_proc, 0.5), pct(t_pop, 0.5),
+           (double)N * chunk * 4 / (pct(t_push, 0.5) * 1e-3) / 1e9, released, wrong, imperfect, uneven);
+    opv_destroy(ctx);
+    (void)hipHostFree(iq);
+    return wrong ? 1 : 0;
+}

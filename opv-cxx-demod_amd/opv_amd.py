@@ -32,7 +32,7 @@ EXPORTS = [
     "opv_attach_device_iq", "opv_process", "opv_sync", "opv_set_frontend", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_comm_unique_id", "opv_comm_init", "opv_comm_init_all",
     "opv_comm_destroy", "opv_gather_frames", "opv_gather_frames_all", "opv_tap_soft", "opv_tap_chunks",
-    "opv_tap_offset_energies", "opv_tap_wave_info", "opv_tap_occupancy", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_bert_frames", "opv_tx_modulated_samples",
+    "opv_tap_offset_energies", "opv_offset_ties_on_host", "opv_tap_wave_info", "opv_tap_occupancy", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_bert_frames", "opv_tx_modulated_samples",
     "opv_tx_modulate", "opv_tap_tx_checkpoints", "opv_frontend_kernel", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device", "opv_tx_modulate_device_to_host",
     "opv_tx_stream_create", "opv_tx_stream_reset", "opv_tx_stream_frames", "opv_tx_stream_tail", "opv_tx_stream_destroy", "opv_tap_tx_frame",
 ]
@@ -128,6 +128,7 @@ def lib():
         L.opv_tap_chunks.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
         L.opv_tap_offset_energies.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.opv_tap_wave_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.opv_offset_ties_on_host.argtypes = [C.c_void_p]
         L.opv_tap_occupancy.argtypes = [C.c_void_p, C.c_void_p]
         L.opv_decode_payloads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
@@ -180,6 +181,23 @@ def comm_create(world, rank, device=0, uid=None):
     comm = C.c_void_p()
     _chk(lib().opv_comm_init(C.byref(comm), world, rank, uid, device))
     return comm, uid
+
+
+def comm_init_all(devices):
+    """opv_comm_init_all: one RCCL communicator per listed GPU inside THIS process (rank i on devices[i]); returns the list"""
+    n = len(devices)
+    comms = (C.c_void_p * n)()
+    devs = (C.c_int * n)(*[int(d) for d in devices])
+    _chk(lib().opv_comm_init_all(comms, n, devs))
+    return [C.c_void_p(comms[i]) for i in range(n)]
+
+
+def gather_frames_all(demods, comms, root, d_frames_all, d_counts_all):
+    """opv_gather_frames_all: the gathers of every context of this process (demods[i] on comms[i]) in one RCCL group"""
+    n = len(demods)
+    ctxs = (C.c_void_p * n)(*[d.h.value for d in demods])
+    cm = (C.c_void_p * n)(*[c.value for c in comms])
+    _chk(lib().opv_gather_frames_all(ctxs, cm, n, root, C.c_void_p(d_frames_all), C.c_void_p(d_counts_all)))
 
 
 def comm_destroy(comm):
@@ -370,6 +388,10 @@ class Demod:
         out = np.zeros(134, np.float64)
         _chk(lib().opv_tap_offset_energies(self.h, stream, out.ctypes.data))
         return out
+
+    def offset_ties_on_host(self):
+        """True when the offset search's near-ties are decided with the host's libm (include/opv_demod.h)"""
+        return bool(lib().opv_offset_ties_on_host(self.h))
 
     def wave_info(self, stream):
         """(HW_ID, XCC_ID, shader cycles, 100 MHz ticks) of the wave that ran the stream's last front-end launch"""

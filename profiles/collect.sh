@@ -10,7 +10,7 @@
 # Everything is written under gpurun_out/profiles_<tag>/ and merged back by gpurun; copy the
 # summaries into profiles/ afterwards (see profiles/README.md).
 TAG=${1:-r02}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 O=$R/gpurun_out/profiles_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev: the 1024-stream question - placement, in-kernel clock and wave cycles of the one-wave front-end
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/anomaly; rm -rf $O; mkdir -p $O
+R=${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}; O=$R/gpurun_out/anomaly; rm -rf $O; mkdir -p $O
 P=$R/scripts/experiments/placement_probe.py
 for S in 64 256 512 1024 2048 4096; do
   timeout 200 python3 $P $S 30 3 2>&1 | grep -v amdgpu.ids | tee -a $O/probe.txt

@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev: instruction / wait counters of the two-waves-per-stream front-end (64 streams x 30 frames)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/dualpmc; rm -rf $O; mkdir -p $O
+R=${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}; O=$R/gpurun_out/dualpmc; rm -rf $O; mkdir -p $O
 P=$R/scripts/experiments/dual_probe.py
 for M in -2 1; do
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-include-regex "k_msk_frontend" --output-format csv -d $O/a$M -- python3 $P 64 30 $M > $O/a$M.log 2>&1

@@ -1,5 +1,5 @@
 # dev: wait/active counters of the front-end kernel for library variants
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   export OPV_LIB=$R/opv-cxx-demod_amd/libopv_$v.so

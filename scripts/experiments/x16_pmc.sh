@@ -2,7 +2,7 @@
 # dev: instruction / wait counters of the sixteen-streams-per-wave front-end (16384 streams x 8 frames) and, for comparison, of
 # the four-per-wave one at the same stream count. Per stream and symbol: counter / (streams x symbols).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/x16pmc; rm -rf $O; mkdir -p $O
+R=${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}; O=$R/gpurun_out/x16pmc; rm -rf $O; mkdir -p $O
 P=$R/scripts/experiments/x4_probe.py
 for CFG in "16384 16" "16384 4"; do
 set -- $CFG

@@ -2,7 +2,7 @@
 # dev: instruction / wait counters of the four-streams-per-wave front-end (4096 and 8192 streams x 30 frames) and, for
 # comparison, of the one-wave-per-stream one at 1024 streams. Per stream and symbol: counter / (streams x symbols).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/x4pmc; rm -rf $O; mkdir -p $O
+R=${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}; O=$R/gpurun_out/x4pmc; rm -rf $O; mkdir -p $O
 P=$R/scripts/experiments/x4_probe.py
 for CFG in "4096 4" "8192 4" "1024 1"; do
 set -- $CFG

@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev helper: PMC passes on the front-end kernel (run through scripts/gpurun_retry.sh)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 O=$R/gpurun_out/pmc
 rm -rf $O; mkdir -p $O
 ARGS="$R/bench.py --streams 64 --frames 20 --steps 1 --warmup 0 --no-extras"

@@ -97,6 +97,12 @@ def main():
                               "stderr_sha256": sha(err.encode())}
         if mode == "stream":
             (HERE / "c1_stream_stderr.txt").write_text(err)
+    # the -h text of the reference binary (src/opv-demod.cpp:962-971), argv[0] normalised
+    _, err, rc = run_demod(b"", ["-h"])
+    assert rc == 0
+    lines = err.split("\n")
+    lines[0] = "Usage: opv-demod [options] < input.iq"
+    (HERE / "usage_stderr.txt").write_text("\n".join(lines))
     out, err, rc = run_demod(iq10, ["-s", "-r", "-q", "-o", "1000"])
     r = ref.receive(iq, streaming=True, init_offset=1000.0)
     assert out == r["frames"].tobytes()

@@ -69,10 +69,58 @@ def offset_openings(seed, n_streams=512):
     return caps
 
 
+def symmetric_openings(seed, n_streams=208):
+    """n_streams captures whose offset-search landscape is EXACTLY symmetric, E(-o) = E(+o) (real-valued or purely imaginary
+    samples): mirrored candidates tie, and in the reference they tie EXACTLY - its LO increments for -o and +o are exact
+    negatives, so c2(-o) = conj(c1(+o)) bit for bit and the strict '>' (src/opv-demod.cpp:161,195) keeps the first, -1500 -
+    while a one-pass evaluation sees two energies 1e-13 apart in either order. The landscape of such a capture is a
+    smooth even function (every feature is a 54 kHz wide window lobe), so it peaks at o = 0 (no tie) or is convex and the two
+    EDGE candidates -1500 / +1500 tie, the coarse winner then dragging the fine pass to -1530 or +1530: real tones outside the
+    tone pair (convex), pairs of them, with and without real noise, real noise alone, and - mostly peaked at 0, the controls - a
+    tone near the pair or one branch of an MSK capture with a carrier offset; random levels and lengths (the search uses
+    min(N, 40 000) samples)."""
+    from oracle_lib import Oracle, impair
+    o = Oracle()
+    rng = np.random.default_rng(seed)
+    base = o.modulate(o.bert_frames(2, "T%d" % (seed % 1000), first=seed))
+    caps = []
+    for k in range(n_streams):
+        n = int(rng.choice([4000, 12000, 24000, 39999, 40000, 40040, 44000]))
+        t = np.arange(n)
+        kind = k % 8
+        amp = float(rng.uniform(200, 15000))
+        if kind in (0, 1):                                       # a real tone outside the pair: convex landscape, the edges tie
+            f = float(rng.uniform(30000, 60000))
+            v = amp * np.cos(2 * np.pi * f * t / 2168000.0 + rng.uniform(0, 6.28))
+        elif kind == 2:                                          # two of them plus real noise
+            v = amp * np.cos(2 * np.pi * rng.uniform(30000, 60000) * t / 2168000.0 + rng.uniform(0, 6.28)) \
+                + 0.5 * amp * np.cos(2 * np.pi * rng.uniform(30000, 60000) * t / 2168000.0 + 1.0) + 0.05 * amp * rng.standard_normal(n)
+        elif kind == 3:                                          # a tone near the pair (peak at 0) against one outside, plus real noise
+            v = rng.uniform(0, 0.3) * amp * np.cos(2 * np.pi * (13550.0 + rng.uniform(-1400, 1400)) * t / 2168000.0) \
+                + amp * np.cos(2 * np.pi * rng.uniform(30000, 60000) * t / 2168000.0 + 1.0) + 0.05 * amp * rng.standard_normal(n)
+        elif kind == 4:                                          # real noise only
+            v = rng.standard_normal(n) * amp * 0.2
+        else:                                                    # one branch of an MSK capture with a carrier offset
+            at = int(rng.integers(0, base.size // 2 - n - 1))
+            x = impair(base[2 * at: 2 * (at + n)], amp=amp, f0_hz=float(rng.uniform(-1500, 1500)),
+                       ebn0_db=None if kind == 5 else float(rng.uniform(3, 25)), seed=seed * 1000 + k)
+            v = x[(kind & 1)::2].astype(np.float64)              # kind 5, 7: Q branch; kind 6: I branch
+        x = np.zeros(2 * n, np.int16)
+        x[(k // 8) % 2::2] = np.clip(np.rint(v), -32768, 32767)  # real-valued (Q = 0) or purely imaginary (I = 0)
+        caps.append(x)
+    return caps
+
+
 def oracle_offset_chunk(caps):
     from oracle_lib import Oracle
     o = Oracle()
     return [o.estimate_offset(c) for c in caps]
+
+
+def oracle_offset_energies_chunk(caps):
+    from oracle_lib import Oracle
+    o = Oracle()
+    return [o.estimate_offset(c, energies=True) for c in caps]
 
 
 def oracle_receive_job(x, want_soft=False):

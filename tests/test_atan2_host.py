@@ -1,14 +1,18 @@
-"""CPU-only: the table-driven atan2 used by the AFC phase detector (csrc/opv_atan2.h), built
-for the host from the same header + table, against glibc atan2."""
+"""CPU-only: the table-driven atan2 routines of the AFC phase detector, built for the host from the same headers + tables the
+kernels use, against glibc atan2: csrc/opv_atan2.h (the product's two), variants/opv_atan2_cmp.h (the comparison build's 33-row
+one), tests/atan/opv_atan2_q3.h (the (k, h) form the shipped 1025-row table was derived from)."""
 import subprocess
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
+INC = ["-I", str(ROOT / "opv-cxx-demod_amd" / "csrc"), "-I", str(ROOT / "opv-cxx-demod_amd" / "variants"), "-I", str(ROOT / "tests" / "atan")]
 SRC = r'''
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include "opv_atan2.h"
+#include "opv_atan2_cmp.h"
+#include "opv_atan2_q3.h"
 int main() {
     double maxabs = 0, maxrel = 0;
     srand48(7);
@@ -39,7 +43,7 @@ def test_atan2_table_matches_libm(tmp_path):
     c = tmp_path / "t.cpp"
     c.write_text(SRC)
     exe = tmp_path / "t"
-    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", str(ROOT / "opv-cxx-demod_amd" / "csrc"), str(c), "-o",
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", *INC, str(c), "-o",
                     str(exe), "-lm"], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     maxabs, maxrel = float(out[0]), float(out[1])
@@ -58,7 +62,7 @@ def test_atan2_q_table_matches_libm(tmp_path):
     c = tmp_path / "t.cpp"
     c.write_text(SRC_Q)
     exe = tmp_path / "t"
-    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", str(ROOT / "opv-cxx-demod_amd" / "csrc"), str(c), "-o",
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", *INC, str(c), "-o",
                     str(exe), "-lm"], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     assert float(out[0]) < 5e-16
@@ -74,7 +78,7 @@ int main() {
     return 0;
 }
 """)
-    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", str(ROOT / "opv-cxx-demod_amd" / "csrc"), str(c), "-o",
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", *INC, str(c), "-o",
                     str(exe), "-lm"], check=True)
     assert subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip() == "1"
 
@@ -83,7 +87,8 @@ def test_table_is_reproducible(tmp_path):
     """The committed tables equal what tools/gen_atan_table.py generates (mpmath, 60 digits)."""
     import shutil
     pkg = ROOT / "opv-cxx-demod_amd"
-    incs = [pkg / "csrc" / "opv_atan_table.inc", pkg / "csrc" / "opv_atan_table_q.inc"]
+    incs = [pkg / "variants" / "opv_atan_table.inc", pkg / "csrc" / "opv_atan_table_q.inc", pkg / "csrc" / "opv_atan_table_q3r.inc",
+            ROOT / "tests" / "atan" / "opv_atan_table_q3.inc"]
     before = [inc.read_text() for inc in incs]
     for k, inc in enumerate(incs):
         shutil.copy(inc, tmp_path / f"keep{k}.inc")
@@ -102,13 +107,13 @@ def test_atan2_q3_table_is_within_its_stated_error(tmp_path):
     c = tmp_path / "t.cpp"
     c.write_text(SRC.replace("opv_atan2(", "opv_atan2_q3("))
     exe = tmp_path / "t"
-    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", str(ROOT / "opv-cxx-demod_amd" / "csrc"), str(c), "-o",
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", *INC, str(c), "-o",
                     str(exe), "-lm"], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     assert float(out[0]) < 1e-13
     chk = tmp_path / "a.cpp"
-    chk.write_text('#include <stdio.h>\n#include "opv_atan2.h"\nint main(){printf("%a %a\\n", opv_atan2_q3(0.0, 1.0), opv_atan2_q3(0.0, 5e7));return 0;}')
-    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", str(ROOT / "opv-cxx-demod_amd" / "csrc"), str(chk), "-o", str(tmp_path / "a"), "-lm"], check=True)
+    chk.write_text('#include <stdio.h>\n#include "opv_atan2_q3.h"\nint main(){printf("%a %a\\n", opv_atan2_q3(0.0, 1.0), opv_atan2_q3(0.0, 5e7));return 0;}')
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", *INC, str(chk), "-o", str(tmp_path / "a"), "-lm"], check=True)
     assert subprocess.run([str(tmp_path / "a")], capture_output=True, text=True, check=True).stdout.split() == ["0x0p+0", "0x0p+0"]
 
 
@@ -122,7 +127,7 @@ def test_atan2_q3r_is_q3_written_in_the_argument(tmp_path):
     c = tmp_path / "t.cpp"
     c.write_text(src)
     exe = tmp_path / "t"
-    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-I", str(ROOT / "opv-cxx-demod_amd" / "csrc"), str(c), "-o",
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", *INC, str(c), "-o",
                     str(exe), "-lm"], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     assert float(out[0]) < 1e-13

@@ -59,12 +59,12 @@ def _world2_env():
     return env
 
 
-def _check_world2_line(p, how, world=2):
+def _check_world2_line(p, how, world=2, backend="gloo"):
     out = ROOT / "gpurun_out"
     out.mkdir(exist_ok=True)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
     with open(out / "bench_world2.txt", "a") as f:
-        f.write(f"$ OPV_BENCH_BACKEND=gloo OPV_BENCH_SHARE_DEVICE=1 {how}\nexit {p.returncode}\n" + "\n".join(lines) + "\n"
+        f.write(("$ OPV_BENCH_BACKEND=gloo OPV_BENCH_SHARE_DEVICE=1 " if backend == "gloo" else "$ ") + f"{how}\nexit {p.returncode}\n" + "\n".join(lines) + "\n"
                 + ("--- stderr tail\n" + p.stderr[-3000:] + "\n" if p.returncode else "") + "\n")
     assert p.returncode == 0, p.stderr[-3000:]
     assert len(lines) == 1, p.stdout[-2000:]          # ONE line, from rank 0 only
@@ -73,7 +73,7 @@ def _check_world2_line(p, how, world=2):
     W = world
     assert line["n_gpus"] == W and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
     c = line["collective"]
-    assert c["backend"] == "gloo" and c["world"] == W
+    assert c["backend"] == backend and c["world"] == W
     assert c["gathered_shape"][0] == W and c["gathered_shape"][1] == S and c["gathered_shape"][3] == 134
     # rank r owns the global streams 8 r .. 8 r + 7 - not a second copy of 0..7: said by the ranks, and read back from the bytes
     assert c["rank_shards"] == [[r * S, (r + 1) * S] for r in range(W)]
@@ -116,6 +116,35 @@ def test_bench_world2_under_the_drivers_launcher(world):
               "--master-port", str(port), str(ROOT / "bench.py")] + args
     p = subprocess.run([sys.executable] + launch, env=_world2_env(), capture_output=True, text=True, timeout=420)
     _check_world2_line(p, "python " + " ".join(launch[:-len(args) - 1]) + " bench.py " + " ".join(args), world=world)
+
+
+def _n_gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()           # (does not initialise a GPU on this image)
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 GPUs: RCCL refuses two ranks on one device (armed for an N-GPU box)")
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_worldN_over_rccl_under_the_drivers_launcher(world):
+    """ARMED FOR AN N-GPU BOX (skipped on the 1-GPU pool): the driver's own N > 1 command with NO rehearsal switch - rank r on
+    cuda:r, init_process_group("nccl") = RCCL over xGMI, the frame gather and the MAX of the step time on device tensors. Same
+    checks as the gloo rehearsal: rank shards, callsigns read back from the gathered bytes, whole-job value."""
+    import socket
+    if _n_gpus() < world:
+        pytest.skip(f"{_n_gpus()} GPUs visible, {world} needed")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in _world2_env().items() if k not in ("OPV_BENCH_BACKEND", "OPV_BENCH_SHARE_DEVICE")}
+    args = ["--gpus", str(world)] + WORLD2_ARGS[2:]
+    launch = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+              "--master-port", str(port), str(ROOT / "bench.py")] + args
+    p = subprocess.run([sys.executable] + launch, env=env, capture_output=True, text=True, timeout=420)
+    _check_world2_line(p, "python " + " ".join(launch[:-len(args) - 1]) + " bench.py " + " ".join(args), world=world, backend="nccl")
 
 
 @pytest.mark.gpu

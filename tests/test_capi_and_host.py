@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(amd):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/opv_demod.h but not exported"
     assert sorted(amd.EXPORTS) == names, "opv_amd.EXPORTS out of sync with the header"
-    assert L.opv_abi_version() == 5
+    assert L.opv_abi_version() == 6
 
 
 def test_struct_layouts_match_header(amd, tmp_path):
@@ -104,6 +104,17 @@ def test_cli_binaries_built_and_usage(amd):
     assert (b / "opv-demod").exists() and (b / "opv-mod").exists()
     r = subprocess.run([str(b / "opv-demod"), "-h"], capture_output=True)
     assert r.returncode == 0 and b"-s" in r.stderr and b"-o <hz>" in r.stderr
+    # the reference's usage text (tests/golden/usage_stderr.txt: made by its binary, ref src/opv-demod.cpp:962-971), line for
+    # line, THEN the two flags the reference does not have (INTEGRATION.md lists them)
+    ref = (ROOT / "tests" / "golden" / "usage_stderr.txt").read_text().rstrip("\n").split("\n")
+    got = r.stderr.decode().rstrip("\n").split("\n")
+    assert got[0].startswith("Usage: ") and got[0].endswith(" [options] < input.iq")
+    assert got[1:len(ref)] == ref[1:]
+    assert [ln.split()[0] for ln in got[len(ref):]] == ["--device", "--capacity-sec"]
+    live = ROOT / "oracle" / "_ref" / "opv-demod"
+    if live.exists():
+        lr = subprocess.run([str(live), "-h"], capture_output=True).stderr.decode().rstrip("\n").split("\n")
+        assert lr[1:] == ref[1:]
     out = subprocess.run([str(b / "opv-mod"), "-S", "W5NYV", "-B", "1"], capture_output=True).stdout
     assert len(out) == (2168 * 40 + 4000) * 4
 
@@ -323,6 +334,56 @@ def test_flat_top_zones_hold_for_this_libm():
             assert abs(f(x0 + e)) == 1.0 and abs(f(x0 - e)) == 1.0, (x0, e)
         for e in below:
             assert abs(f(x0 + e)) < 1.0 and abs(f(x0 - e)) < 1.0, (x0, e)
+
+
+def test_offset_tie_host_evaluation_is_the_reference_evaluation(oracle, tmp_path):
+    """csrc/opv_offset_host.cpp (the product's host-side decision of offset-search near-ties) against the oracle's
+    estimate_offset (ref src/opv-demod.cpp:131-202), on this machine's libm: the energy of every coarse candidate EQUAL bit for bit
+    on a noisy MSK opening and on a real-valued (exactly tying) one; the pinned probe energy is the oracle's table entry for
+    the probe sequence; and the whole decision, fed a polynomial whose values tie at the edges, keeps the reference's first
+    maximum."""
+    import subprocess
+    pkg = ROOT / "opv-cxx-demod_amd"
+    so = tmp_path / "libtie.so"
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", str(so), str(pkg / "csrc" / "opv_offset_host.cpp")], check=True)
+    syms = subprocess.run(["nm", "-D", "--defined-only", str(so)], capture_output=True, text=True, check=True).stdout.split()
+    name = lambda part: next(x for x in syms if part in x)
+    L = C.CDLL(str(so))
+    energy = getattr(L, name("opv_offset_candidate_energy"))
+    energy.restype = C.c_double
+    energy.argtypes = [C.c_void_p, C.c_size_t, C.c_double]
+    probe = getattr(L, name("opv_offset_host_libm_matches_reference"))
+    probe.restype = C.c_bool
+    decide = getattr(L, name("opv_offset_decide_on_host"))
+    decide.restype = C.c_double
+    decide.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert probe()                                               # this image's glibc gives the pinned energy
+    # the probe sequence and its pinned energy (csrc/opv_offset_host.h) against the oracle's table
+    v, seq = 0x2545F491, np.empty(80000, np.int16)
+    for k in range(80000):
+        v = (v * 1664525 + 1013904223) & 0xFFFFFFFF
+        seq[k] = (v >> 16) % 4001 - 2000
+    hdr = (pkg / "csrc" / "opv_offset_host.h").read_text()
+    pinned = float.fromhex(re.search(r"OPV_OFFSET_PROBE_ENERGY (0x[0-9a-fp.+]+)", hdr).group(1))
+    _, e = oracle.estimate_offset(seq, energies=True)
+    assert e[117] == pinned == energy(seq.ctypes.data, 1000, 1425.0)
+    from oracle_lib import impair
+    iq = oracle.modulate(oracle.bert_frames(1))
+    noisy = np.ascontiguousarray(impair(iq[: 2 * 30000], amp=1500.0, f0_hz=640.0, ebn0_db=9.0, seed=3))
+    real = np.zeros(2 * 40000, np.int16)
+    real[0::2] = np.rint(9000 * np.cos(2 * np.pi * 36000.0 * np.arange(40000) / 2168000.0 + 0.3))
+    for x in (noisy, real):
+        off, e = oracle.estimate_offset(x, energies=True)
+        nsym = min(x.size // 2, 40000) // 40
+        mine = np.array([energy(x.ctypes.data, nsym, -1500.0 + 25.0 * c) for c in range(121)])
+        assert np.array_equal(mine, e[:121])
+    assert e[0] == e[120] and off == -1530.0                     # the real-valued capture: an exact mirror tie, first maximum kept
+    # the decision: a polynomial in theta whose values at the edge candidates are the winners and equal (even, convex)
+    poly = np.zeros(19)
+    poly[0], poly[2] = e[60], (e[0] - e[60]) / (2 * np.pi * 1500.0 / 2168000.0) ** 2
+    out, ties = np.zeros(134), C.c_uint32(0)
+    est = decide(real.ctypes.data, 1000, poly.ctypes.data, out.ctypes.data, C.byref(ties))
+    assert est == off and ties.value >= 2 and out[0] == e[0] and out[120] == e[120]
 
 
 def test_rx_bridge_rejects_a_malformed_device_list(amd):

@@ -47,7 +47,10 @@ def _worker(rank, world, port, total_streams, cap, q):
 def test_shard_and_gather_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29000 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:                        # an OS-assigned free port (a pid-derived one collides between concurrent jobs)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, 8, 4, q)) for r in range(2)]
     for p in procs:
         p.start()

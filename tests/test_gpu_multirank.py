@@ -26,19 +26,39 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _rank_main(rank, world, port, per_rank, n_frames, ebn0, q):
+def _n_gpus():
+    """GPUs visible to this job, without initialising one (torch.cuda.device_count() does not, on this image)"""
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+NEEDS_2_GPUS = pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 GPUs: RCCL refuses two ranks on one device (armed for an N-GPU box; "
+                                                        "the 1-GPU pool runs the same code over gloo / at world 1)")
+
+
+def _rank_main(rank, world, port, per_rank, n_frames, ebn0, q, backend="gloo"):
+    """one rank of the real pipeline. backend "gloo": every rank on cuda:0, host-side collectives (the one-GPU rehearsal);
+    backend "nccl": rank r on cuda:r, RCCL collectives on device tensors - what bench.py does on an N-GPU node."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
     import torch.distributed as dist
     from __graft_entry__ import load_opv_amd, load_pkg_module
     from oracle_lib import Oracle
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    amd, sharding, workload = load_opv_amd(), load_pkg_module("sharding"), load_pkg_module("workload")
-    dev = torch.device("cuda", 0)
+    dev_index = rank if backend == "nccl" else 0
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = (lambda t: t.to(dev)) if backend == "nccl" else (lambda t: t)      # RCCL moves device tensors only
+    amd, sharding, workload = load_opv_amd(), load_pkg_module("sharding"), load_pkg_module("workload")
     mine = sharding.stream_range(rank, world, world * per_rank)
     n = amd.lib().opv_tx_modulated_samples(n_frames)
-    dm = amd.Demod(per_rank, max_samples=n + 64, streaming=True, device=0)
+    dm = amd.Demod(per_rank, max_samples=n + 64, streaming=True, device=dev_index)
     d_iq, tx, n = workload.generate(amd, dm, torch, dev, mine, n_frames, ebn0)
     for k in range(per_rank):
         dm.attach(k, d_iq[k].data_ptr(), n, eof=True)
@@ -64,19 +84,24 @@ def _rank_main(rank, world, port, per_rank, n_frames, ebn0, q):
         got_meta[k, :len(fr), 0] = torch.from_numpy(meta["viterbi_metric"].astype(np.int64))
         got_meta[k, :len(fr), 1] = torch.from_numpy(meta["release_symbol"].astype(np.int64))
     fa, ca = sharding.gather_frames(frames_view, counts_view, dst=0)          # the product's gather (device views)
-    ea, eca = sharding.gather_frames(exp_frames, exp_counts, dst=0)
+    ea, eca = sharding.gather_frames(comm(exp_frames), comm(exp_counts), dst=0)
+    got_meta, exp_meta = comm(got_meta), comm(exp_meta)
     ml = [torch.empty_like(got_meta) for _ in range(world)] if rank == 0 else None
     el = [torch.empty_like(exp_meta) for _ in range(world)] if rank == 0 else None
     dist.gather(got_meta, ml, dst=0)
     dist.gather(exp_meta, el, dst=0)
     if rank == 0:
+        if backend == "nccl":
+            assert fa.is_cuda and fa.device == dev              # the gather landed in rank 0's HBM, not in host memory
         got, exp = sharding.flatten_global(fa, ca), sharding.flatten_global(ea, eca)
-        ok = len(got) == world * per_rank and bool((ca == eca).all())
+        ok = len(got) == world * per_rank and bool((ca.cpu() == eca.cpu()).all())
         n_frames_total = 0
         for g in range(world * per_rank):
-            ok &= bool(torch.equal(got[g].cpu(), exp[g]))
+            ok &= bool(torch.equal(got[g].cpu(), exp[g].cpu()))
             n_frames_total += len(got[g])
-        ok &= bool(torch.equal(torch.stack(ml), torch.stack(el)))
+        ok &= bool(torch.equal(torch.stack(ml).cpu(), torch.stack(el).cpu()))
+        # and who sent what: the Base-40 callsign of every global stream's first frame is S<g> (workload.stream_params)
+        ok &= [amd.callsign_of(got[g][0].cpu().numpy()) for g in range(world * per_rank)] == [f"S{g}" for g in range(world * per_rank)]
         q.put((bool(ok), n_frames_total))
     dm.close()
     dist.barrier()
@@ -86,19 +111,93 @@ def _rank_main(rank, world, port, per_rank, n_frames, ebn0, q):
 def test_world2_real_pipeline_every_global_stream_vs_oracle():
     """two processes, each opv_process on its contiguous shard of 8 streams (16 global streams x 12 frames,
     16 dB, f0 -2000..-1048 Hz), frames gathered to rank 0 by sharding.gather_frames"""
+    ok, nfr = _run_ranks(2, "gloo")
+    assert ok is True
+    assert nfr >= 16 * 11, nfr
+
+
+def _run_ranks(world, backend, per_rank=8, n_frames=12):
     import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
+    ctx = mp.get_context("spawn")                          # fresh interpreters: nothing of this process's GPU state is inherited
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, 8, 12, 16.0, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, per_rank, n_frames, 16.0, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
-    ok, nfr = q.get(timeout=10)
-    assert ok is True
-    assert nfr >= 16 * 11, nfr
+    return q.get(timeout=10)
+
+
+def test_real_pipeline_rank_code_under_nccl_world_1():
+    """the rank function of the N > 1 RCCL test below, run where it can run on one GPU: backend "nccl" with ONE rank
+    (device_id init, device-tensor gathers of the oracle's side, the landing-in-HBM assertion) - so that the armed test is
+    not the first execution of any of its lines except the second rank."""
+    ok, nfr = _run_ranks(1, "nccl")
+    assert ok is True and nfr >= 8 * 11, nfr
+
+
+@NEEDS_2_GPUS
+@pytest.mark.parametrize("world", [2, 4])          # (ranks + this process stay within the pool's six GPU processes per job)
+def test_worldN_real_pipeline_over_rccl_every_global_stream_vs_oracle(world):
+    """ARMED FOR AN N-GPU BOX (skipped on the 1-GPU pool): BASELINE configs[4] as north_star words it - one process per GPU,
+    rank r on cuda:r, init_process_group("nccl") = RCCL over xGMI, each rank's opv_process on its contiguous shard of 8
+    streams, ONE gather of the decoded frames to rank 0 - and every GLOBAL stream's frames, Viterbi metrics and sync
+    positions against the oracle run on that stream's own bytes (streams are independent: ref src/opv-demod.cpp:999-1001)."""
+    if _n_gpus() < world:
+        pytest.skip(f"{_n_gpus()} GPUs visible, {world} needed")
+    ok, nfr = _run_ranks(world, "nccl")
+    assert ok is True and nfr >= world * 8 * 11, nfr
+
+
+@NEEDS_2_GPUS
+def test_c_side_gather_frames_all_over_two_devices():
+    """ARMED FOR AN N-GPU BOX: the C ABI's one-process-many-GPUs form (include/opv_demod.h: opv_comm_init_all +
+    opv_gather_frames_all, the N ranks' ncclGathers issued by one thread inside one RCCL group): a context per device, each on
+    its own shard of 6 streams, frames and counts gathered into device 0's HBM; the gathered [N][S][cap][134] / [N][S] equal
+    every context's own buffers and every global stream's frames the oracle's."""
+    import torch
+    from __graft_entry__ import load_opv_amd, load_pkg_module
+    from oracle_lib import Oracle
+    amd, workload = load_opv_amd(), load_pkg_module("workload")
+    N = min(_n_gpus(), 4)
+    S, F = 6, 5
+    n = amd.lib().opv_tx_modulated_samples(F)
+    dms, iqs, views = [], [], []
+    for r in range(N):
+        dev = torch.device("cuda", r)
+        with torch.cuda.device(dev):
+            dm = amd.Demod(S, max_samples=n + 64, streaming=True, device=r)
+            d_iq, tx, n = workload.generate(amd, dm, torch, dev, range(r * S, (r + 1) * S), F, 16.0)
+            for k in range(S):
+                dm.attach(k, d_iq[k].data_ptr(), n, eof=True)
+            dm.process()
+            dms.append(dm)
+            iqs.append(d_iq)
+            views.append(workload.frame_views(dm, torch, dev))
+    cap = views[0][0].shape[1]
+    dev0 = torch.device("cuda", 0)
+    fa = torch.full((N, S, cap, 134), 0xEE, dtype=torch.uint8, device=dev0)
+    ca = torch.full((N, S), -7, dtype=torch.int32, device=dev0)
+    torch.cuda.synchronize(dev0)
+    comms = amd.comm_init_all(list(range(N)))
+    amd.gather_frames_all(dms, comms, 0, fa.data_ptr(), ca.data_ptr())
+    for dm in dms:
+        dm.sync()
+    o = Oracle()
+    for r in range(N):
+        fv, cv = views[r]
+        assert bool(torch.equal(fa[r].cpu(), fv.cpu())) and bool(torch.equal(ca[r].cpu(), cv.cpu())), r
+        host = iqs[r].cpu().numpy()
+        for k in range(S):
+            e = o.receive(host[k], streaming=True, want_soft=False)
+            assert int(ca[r, k]) == len(e["frames"]) and np.array_equal(fa[r, k, :len(e["frames"])].cpu().numpy(), e["frames"]), (r, k)
+            assert amd.callsign_of(e["frames"][0]) == f"S{r * S + k}"
+    for c in comms:
+        amd.comm_destroy(c)
+    for dm in dms:
+        dm.close()
 
 
 def test_bench_rccl_leg_executes_at_world_1(request):
@@ -258,9 +357,11 @@ def test_512_stream_context_vs_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("S", [522, 2060, 8200])
+@pytest.mark.parametrize("S", [522, 2060, 8200, 16400])
 def test_many_stream_contexts_on_the_automatic_mapping(S):
-    """8200 streams: beyond 8192 the shim takes sixteen streams per wave by itself (k_msk_frontend_x16_wg4: 128 full workgroups
+    """16 400 streams: beyond 16 384 the sixteen-per-wave kernel runs EIGHT waves (128 streams, 8 rings + the table = 151 600 B of
+    LDS) per workgroup (k_msk_frontend_x16_wg8: 128 full workgroups + one with 16 streams, i.e. one busy wave and seven that have
+    nothing to do). 8200 streams: beyond 8192 the shim takes sixteen streams per wave by itself (k_msk_frontend_x16_wg4: 128 full workgroups
     of 64 streams + one with 8, i.e. a wave with eight idle quads and three waves that have nothing to do). 522 streams: one wave per stream, FOUR waves per workgroup (k_msk_frontend_rb_wg4, from 513 streams; 130 full
     workgroups + a partly filled one). 2060 streams: more than the one-wave-per-stream kernel holds in two rounds, the
     shim takes the four-per-wave mapping by itself (from 2049 streams; 128 full workgroups + a partly filled one, and
@@ -279,7 +380,7 @@ def test_many_stream_contexts_on_the_automatic_mapping(S):
         dm.attach(k, d_iq[k % D].data_ptr(), n, eof=True)
     dm.process()
     dm.sync()
-    assert dm.frontend_kernel() == {522: "k_msk_frontend_rb_wg4", 2060: "k_msk_frontend_x4_wg4", 8200: "k_msk_frontend_x16_wg4"}[S] or os.environ.get("OPV_FRONTEND")
+    assert dm.frontend_kernel() == {522: "k_msk_frontend_rb_wg4", 2060: "k_msk_frontend_x4_wg4", 8200: "k_msk_frontend_x16_wg4", 16400: "k_msk_frontend_x16_wg8"}[S] or os.environ.get("OPV_FRONTEND")
     host = d_iq.cpu().numpy()
     o = Oracle()
     exp = [o.receive(host[j], streaming=True, want_soft=False) for j in range(D)]

@@ -266,13 +266,57 @@ def test_offset_search_near_tie_guard(amd, oracle, iq10):
         assert st.est_offset_hz == off, k
         assert rel < 1e-11, k
         n_guarded += st.offset_ties >= 2
+        if d.offset_ties_on_host():           # what the host re-evaluated IS the reference's number (same loop, same libm)
+            assert int(np.sum(g == e)) >= st.offset_ties - 1, (k, int(np.sum(g == e)), st.offset_ties)
     assert n_guarded >= 4, n_guarded           # the symmetric landscapes must have been noticed
+    assert d.offset_ties_on_host()             # this image's glibc reproduces the pinned energy (csrc/opv_offset_host.cpp)
     d.close()
     # and on an ordinary capture the guard stays out of the way
     d = amd.Demod(1, max_samples=iq10.size // 2 + 64, streaming=True)
     d.receive([iq10])
     assert d.state(0).offset_ties == 0
     d.close()
+
+
+@pytest.mark.parametrize("host", [True, False])
+def test_offset_search_ties_decided_like_the_reference(amd, host, monkeypatch):
+    """208 captures with an exactly symmetric search landscape (real-valued or purely imaginary samples: tones near and far from
+    the tone pair, noise, single branches of MSK captures; soak_inputs.symmetric_openings) in one batch-mode context: mirrored
+    candidates tie - exactly, in the reference (bit-identical energies for -o and +o: its strict '>', src/opv-demod.cpp:161,195,
+    keeps the first), within 1e-13 in either order in the one-pass evaluation. The guard must notice and re-evaluate; with the
+    tie decided on the host (the reference's loop on the reference's libm, csrc/opv_offset_host.cpp) the estimate equals the oracle's
+    for every capture and every re-evaluated energy IS the oracle's, bit for bit. host=False (OPV_OFFSET_DISTRUST_LIBM: the
+    device's sincos re-evaluates, the fallback for a host with another libm) must give the same estimates here - an exact
+    mirror tie survives any sin / cos that is odd / even in its argument - but not the same last bits of the energies."""
+    from concurrent.futures import ProcessPoolExecutor
+    from soak_inputs import host_workers, oracle_offset_energies_chunk, symmetric_openings
+    S = 208
+    caps = symmetric_openings(int(os.environ.get("OPV_FUZZ_BASE", "20261003")) % 1000 + 23, S)
+    if not host:
+        monkeypatch.setenv("OPV_OFFSET_DISTRUST_LIBM", "1")
+    d = amd.Demod(S, max_samples=46000, streaming=False)
+    assert d.offset_ties_on_host() == host
+    d.receive(caps)
+    got = [d.state(k) for k in range(S)]
+    taps = [d.offset_energies(k) for k in range(S)]
+    d.close()
+    W = host_workers()
+    with ProcessPoolExecutor(W) as ex:
+        res = list(ex.map(oracle_offset_energies_chunk, [caps[i::W] for i in range(W)]))
+    exp = [None] * S
+    for i, part in enumerate(res):
+        exp[i::W] = part
+    guarded = wrong = 0
+    for k in range(S):
+        off, e = exp[k]
+        guarded += got[k].offset_ties >= 2
+        if got[k].est_offset_hz != off:
+            wrong += 1
+        if host and got[k].offset_ties:
+            assert int(np.sum(taps[k] == e)) >= got[k].offset_ties - 1, (k, got[k].offset_ties)
+        assert np.max(np.abs(taps[k] - e) / np.maximum(e, 1e-300)) < 1e-11, k
+    print(f"symmetric captures: {guarded} of {S} guarded, host={host}: {wrong} estimates differ from the oracle's")
+    assert guarded >= S // 3 and wrong == 0, (guarded, wrong)
 
 
 @pytest.mark.parametrize("tag", ["clean", "p700_16dB_pll20"])
@@ -1001,6 +1045,59 @@ def test_rx_bridge_shards_over_contexts_and_gathers_in_cxx(amd, oracle, tmp_path
         assert np.array_equal(got, exps[k]), k
     for so in socks:
         so.close()
+
+
+def _visible_gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()           # (does not initialise a GPU on this image)
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason="needs >= 2 GPUs (armed for an N-GPU box): opv-rx-bridge --devices 0,1 --gather")
+def test_rx_bridge_gathers_over_two_devices_in_cxx(amd, oracle, tmp_path):
+    """ARMED FOR AN N-GPU BOX (skipped on the 1-GPU pool): the stand-alone C++ host on two real devices - `opv-rx-bridge --devices
+    0,1 --gather`: five inputs land 3 + 2 on a context per GPU, and the path's one collective (opv_comm_init_all +
+    opv_gather_frames_all: two ncclGathers in one RCCL group, into GPU 0's HBM) returns every context's frame counts. Datagrams
+    equal the oracle's frames; the bridge's own comparison of gathered and local counts reports no difference."""
+    import socket
+    import subprocess
+    base = 42000 + (os.getpid() % 1500) * 5
+    S = 5
+    socks = []
+    for k in range(S):
+        so = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        so.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1 << 22)
+        so.bind(("127.0.0.1", base + k))
+        so.setblocking(False)
+        socks.append(so)
+    caps, exps = [], []
+    for k in range(S):
+        x = oracle.modulate(oracle.bert_frames(6 + 2 * k, f"E{k}", 0xBBAADD, 7 * k))
+        if k % 2:
+            x = impair(x, amp=3000.0, f0_hz=-500.0 + 300.0 * k, ebn0_db=15.0, seed=20 + k)
+        f = tmp_path / f"e{k}.iq"
+        x.tofile(f)
+        caps.append(str(f))
+        exps.append(oracle.receive(x, streaming=True)["frames"])
+    exe = str(amd.PKG / "bin" / "opv-rx-bridge")
+    r = subprocess.run([exe, "-P", str(base), "--devices", "0,1", "--gather"] + caps, capture_output=True, timeout=300)
+    err = r.stderr.decode()
+    assert r.returncode == 0, err
+    assert "3 per context on 2 contexts" in err, err
+    total = sum(len(e) for e in exps)
+    assert f"gather: 2 rank(s) x 3 stream(s) -> GPU 0 over RCCL: {total} frames released in all, 0 stream(s) differ" in err, err
+    for k in range(S):
+        got = []
+        while True:
+            try:
+                got.append(socks[k].recv(2048))
+            except BlockingIOError:
+                break
+        got = np.frombuffer(b"".join(got), np.uint8).reshape(-1, FRAME_BYTES)
+        assert np.array_equal(got, exps[k]), f"--devices 0,1 stream {k}: {len(got)} datagrams vs {len(exps[k])} frames"
+        socks[k].close()
 
 
 def test_rx_bridge_udp_and_stdin_sources(amd, oracle, tmp_path):
