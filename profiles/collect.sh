@@ -6,15 +6,14 @@
 #                                       MI355X_MICROARCH.md §HBM: FETCH_SIZE x2 for wide reads)
 #   profiles/<tag>_traffic.json         HBM bytes per launch + issued instructions per symbol of k_msk_frontend,
 #                                       derived from those passes (read by bench.py for roofline.traffic / .issue)
-#   profiles/<tag>_bench.json           the bench line of the un-profiled run
+#   profiles/<tag>_bench.json           the bench line of the un-profiled run (made last, so that it carries this collection's counters)
 # Everything is written under gpurun_out/profiles_<tag>/ and merged back by gpurun; copy the
 # summaries into profiles/ afterwards (see profiles/README.md).
-TAG=${1:-r02}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:?run on the GPU box through gpurun}
 O=$R/gpurun_out/profiles_$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 900 python3 $R/bench.py 2>/dev/null | tail -1 > $O/${TAG}_bench.json
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --no-extras > $O/kt.log 2>&1
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv
 agg() { python3 - "$1" <<'PY'
@@ -46,7 +45,7 @@ K = "k_msk_frontend_rb"            # the front-end kernel the shim launches for 
 n_sym = S * 2168099.0                     # symbols one launch demodulates (86 724 000 samples per stream, ~40 per symbol)
 fetch, write = val(1, K, "FETCH_SIZE"), val(2, K, "WRITE_SIZE")
 ips = {k: round(val(3, K, c) / n_sym, 2) for k, c in (("valu", "SQ_INSTS_VALU"), ("salu", "SQ_INSTS_SALU"), ("lds", "SQ_INSTS_LDS"))}
-out = {"kernel": K, "workload": {"streams_per_gpu": S, "frames_per_stream": F, "ebn0": 16.0},
+out = {"kernel": K, "workload": {"streams_per_gpu": S, "frames_per_stream": F, "ebn0": 16.0, "f0_edge_hz": 2000.0},   # SURVEY.md 8(d) C4 as written (workload.py)
        "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
        "hbm_read_bytes_per_launch": fetch * 1024 * 2, "hbm_write_bytes_per_launch": write * 1024,
        "hbm_bytes_per_launch": fetch * 1024 * 2 + write * 1024,
@@ -56,4 +55,8 @@ out = {"kernel": K, "workload": {"streams_per_gpu": S, "frames_per_stream": F, "
 json.dump(out, open(f"{O}/{TAG}_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
+# the un-profiled bench line LAST, with this collection's traffic / instruction counts in place (bench.py reads the newest
+# profiles/rNN_traffic.json and attaches it when kernel and workload match)
+cp $O/${TAG}_traffic.json $R/profiles/${TAG}_traffic.json
+timeout 900 python3 $R/bench.py 2>$O/bench.err | tail -1 > $O/${TAG}_bench.json
 cat $O/${TAG}_bench.json | head -c 600; echo; head -8 $O/${TAG}_kernel_stats.csv; cat $O/${TAG}_pmc_*.txt

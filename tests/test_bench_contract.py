@@ -16,6 +16,12 @@ def test_recorded_bench_line_has_the_contract_shape():
     assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "f64"
     assert line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
     assert line["config"]["workload"].startswith("configs[3]: 64 concurrent IQ streams")
+    assert "f0 -2000..+2000 Hz" in line["config"]["workload"]            # SURVEY.md 8(d) C4 as written: the edge streams on the AFC clamp
+    # the contract's figures are total-time ones; the median of the (>= 5) timed steps stands next to them
+    m = line["median"]
+    assert line["steps"] >= 5 and len(m["step_ms"]) == line["steps"]
+    assert abs(m["ms_per_step"] - sorted(m["step_ms"])[len(m["step_ms"]) // 2]) < 1e-6
+    assert abs(m["value"] - line["value"]) < 0.02 * line["value"]
     # value = samples of all streams x steps / time
     n = line["config"]["samples_per_stream"] * line["config"]["streams_per_gpu"] * line["n_gpus"]
     assert abs(line["value"] - n / (line["ms_per_step"] * 1e-3) / 1e6) < 0.01 * line["value"]
@@ -28,12 +34,21 @@ def test_recorded_bench_line_has_the_contract_shape():
     assert abs(r["achieved"] - algo / (r["kernel_ms"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] >= 0.99 * r["achieved"]    # measured HBM bytes are never below the algorithmic ones
     assert r["issue"]["wave_cycles_per_symbol"] > 600 and 2.0 < r["issue"]["clock_GHz"] < 2.5
+    # the bound that BINDS is named in the object (64 waves on 1024 SIMDs: a lone wave's issue port), HBM stays the contract's figure
+    b = r["binding"]
+    assert b["bound"] == "wave-issue" and b["waves"] == 64 and b["simds"] == 1024
+    assert 0.5 < b["frac"] <= 1.0 and abs(b["frac"] - b["achieved"] / b["peak"]) < 2e-3 and b["frac"] == r["issue"]["wave_issue_frac"]
+    assert b["frac"] > 100 * r["frac"]                                   # (what the HBM fraction alone would hide)
     assert r["fp64_valu"]["peak"] == 78.6 and r["fp64_valu"]["unit"] == "TFLOP/s"
     c = line["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and 1.0 < c["value"] < 200.0
     assert line["check"]["edge_ties"] == 0 and line["check"]["frames_exact"] >= 0.99 * line["check"]["frames_total"]
+    ac = line["extras"]["all_clean_variant"]                              # C4's "all-clean variant": every frame exact and perfect
+    assert ac["frames_exact"] == ac["frames_total"] == ac["frames_perfect"] == 64000 and ac["steps"] >= 5
+    lc = line["extras"]["live_capacity"]
+    assert lc["streams"] >= 512 and lc["round_ms_p99"] < 40.0 and all(p.get("frames_wrong", 0) == 0 for p in lc["probes"])
 
 
 # ----------------------------------------------------------------------------------------------------------------------
