@@ -128,7 +128,8 @@ def live_capacity(dev_index):
     """The reference's real caller shape (`opv-modem -R`, src/opv-modem.cpp:673-838: IQ arrives at 2.168 MSPS, 40 ms per frame), for N
     streams at once: how many live streams ONE context serves in real time. bin/opv-live-capacity (host/opv_live_capacity.cpp, a
     C++ caller of the C ABI like opv-rx-bridge) runs 120 serving rounds - one 86 720-sample chunk per stream pushed from pinned host
-    memory over PCIe, opv_process, every stream's frames popped and compared - and reports the round-time distribution; the
+    memory over PCIe (every stream's chunk at its own host addresses: N x 347 KB of distinct memory per round), opv_process, every
+    stream's frames popped and compared with what was sent - and reports the round-time distribution; the
     capacity is the largest N probed whose p99 round stays under the 40 ms of signal a round consumes. Doubling, then bisection
     to 256 streams."""
     exe = ROOT / "opv-cxx-demod_amd" / "bin" / "opv-live-capacity"
@@ -144,8 +145,8 @@ def live_capacity(dev_index):
         r = probes[n]
         return "error" not in r and r["round_ms_p99"] < 40.0 and r["frames_wrong"] == 0
     lo, hi = 0, None
-    n = 512
-    while n <= 8192:
+    n = 1024
+    while n <= 16384:
         if probe(n):
             lo = n
             n *= 2

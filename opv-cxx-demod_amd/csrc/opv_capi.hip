@@ -109,6 +109,71 @@ __global__ void k_collect_counts(const OpvStream* streams, int32_t* counts, int 
     }
 }
 
+// ---- the serving path's two bulk moves (a live server pushes one 40 ms chunk per stream and round: N separate 347 KB blocks) ----
+// k_push_gather: host -> device for MANY streams in one launch. The sources are the caller's buffers in pinned host memory, read
+// through their device-visible addresses (16 B per lane over PCIe); the table itself lives in pinned memory too. One
+// hipMemcpyAsync per stream moves 1536 such blocks at 21 GB/s (per-copy overhead), this kernel at 57 - the link's rate for one
+// large copy (scripts/microbench/h2d_many.hip). A pair is split into `slices` work items so that few streams still keep
+// enough loads in flight.
+struct PushPair {
+    const void* src;     // device-visible address of the caller's samples
+    void* dst;           // where they go in the stream's device buffer
+    uint32_t bytes;      // multiple of 4 (one sample)
+    uint32_t wide;       // 1: src and dst are 16-byte aligned (int4 moves + a tail of ints), 0: 4-byte moves
+};
+__global__ __launch_bounds__(256) void k_push_gather(const PushPair* tab, uint32_t n_pairs, uint32_t slices) {
+    for (uint32_t w = blockIdx.x; w < n_pairs * slices; w += gridDim.x) {
+        const PushPair p = tab[w / slices];
+        const uint32_t sl = w % slices;
+        if (p.wide) {
+            const uint32_t quads = p.bytes >> 4, per = (quads + slices - 1) / slices;
+            const uint32_t lo = sl * per, hi = lo + per < quads ? lo + per : quads;
+            const int4* s4 = (const int4*)p.src;
+            int4* d4 = (int4*)p.dst;
+            for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) d4[i] = s4[i];
+            if (sl == 0) {                                  // at most three samples behind the last full quad
+                const uint32_t rem = (p.bytes & 15u) >> 2;
+                if (threadIdx.x < rem) ((int*)p.dst)[quads * 4 + threadIdx.x] = ((const int*)p.src)[quads * 4 + threadIdx.x];
+            }
+        } else {
+            const uint32_t words = p.bytes >> 2, per = (words + slices - 1) / slices;
+            const uint32_t lo = sl * per, hi = lo + per < words ? lo + per : words;
+            for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) ((int*)p.dst)[i] = ((const int*)p.src)[i];
+        }
+    }
+}
+// k_compact: the retained tails of MANY streams' staging buffers across to their second buffers in one launch, and the streams'
+// device contexts re-based (what compact_stream does for one stream with two copies). Exactly `samples` samples move: what lies
+// behind them belongs to the pushes that follow on the copy stream.
+struct CompactItem {
+    const int* src;      // retained tail in the full buffer (16-byte aligned: `keep` is a multiple of 4 samples)
+    int* dst;            // head of the other buffer
+    uint32_t samples;
+    uint32_t stream;
+    uint64_t keep;       // samples dropped in front
+};
+__global__ __launch_bounds__(256) void k_compact(OpvStream* streams, const CompactItem* items, uint32_t n_items, uint32_t slices) {
+    for (uint32_t w = blockIdx.x; w < n_items * slices; w += gridDim.x) {
+        const CompactItem it = items[w / slices];
+        const uint32_t sl = w % slices;
+        const uint32_t quads = it.samples >> 2, per = (quads + slices - 1) / slices;
+        const uint32_t lo = sl * per, hi = lo + per < quads ? lo + per : quads;
+        const int4* s4 = (const int4*)it.src;
+        int4* d4 = (int4*)it.dst;
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) d4[i] = s4[i];
+        if (sl == 0) {
+            if (threadIdx.x < (it.samples & 3u)) it.dst[quads * 4 + threadIdx.x] = it.src[quads * 4 + threadIdx.x];
+            if (threadIdx.x == 0) {
+                OpvStream& st = streams[it.stream];
+                st.iq = (const int16_t*)it.dst;
+                st.origin -= it.keep;
+                st.n_avail -= it.keep;
+                st.iq_base += it.keep;
+            }
+        }
+    }
+}
+
 __global__ void k_fill_i32(int32_t* p, int32_t v, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -166,6 +231,9 @@ struct opv_ctx {
     uint32_t* h_tie_list = nullptr;     // pinned, 1 + n_streams words
     bool host_ties = false;             // the host's libm reproduces the pinned reference energy (probed at opv_create)
     std::vector<int16_t> tie_iq;        // <= 40 000 samples of the stream being decided
+    // opv_push_iq_batch: the table of the gather kernel / of the batched compaction, in pinned memory (the kernels read it in place)
+    void* h_bulk_tab = nullptr;
+    size_t bulk_tab_bytes = 0;
     uint64_t cap_soft = 0;
     uint32_t cap_frames = 0, cap_events = 0, cap_chunks = 0;
     bool mirror_valid = false;
@@ -397,6 +465,7 @@ extern "C" void opv_destroy(opv_ctx* c) {
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_stall) (void)hipHostFree(c->h_stall);
     if (c->h_tie_list) (void)hipHostFree(c->h_tie_list);
+    if (c->h_bulk_tab) (void)hipHostFree(c->h_bulk_tab);
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& h : c->hs) {
@@ -447,7 +516,70 @@ static int compact_stream(opv_ctx* c, int s) {
     return OPV_OK;
 }
 
-static int push_enqueue(opv_ctx* c, int s, const int16_t* iq, size_t n) {
+// grow-only pinned table for the two bulk kernels: [CompactItem x n][PushPair x n]. k_compact (on `stream`) may still read its
+// half when the next batch arrives; that half is rewritten only behind a refresh() (which waits for `stream`), the other half
+// only behind the wait for the copy stream that ends every batch.
+static int bulk_table(opv_ctx* c, size_t n, CompactItem** items, PushPair** pairs) {
+    const size_t need = n * (sizeof(CompactItem) + sizeof(PushPair));
+    if (c->bulk_tab_bytes < need) {
+        HIPCHK(hipStreamSynchronize(c->copy_stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->h_bulk_tab) HIPCHK(hipHostFree(c->h_bulk_tab));
+        c->h_bulk_tab = nullptr;
+        c->bulk_tab_bytes = 0;
+        const size_t cap = need < 65536 ? 65536 : 2 * need;
+        HIPCHK(hipHostMalloc(&c->h_bulk_tab, cap, hipHostMallocDefault));
+        c->bulk_tab_bytes = cap;
+    }
+    const size_t per = c->bulk_tab_bytes / (sizeof(CompactItem) + sizeof(PushPair));
+    *items = (CompactItem*)c->h_bulk_tab;
+    *pairs = (PushPair*)((char*)c->h_bulk_tab + per * sizeof(CompactItem));
+    return OPV_OK;
+}
+
+// compact_stream for MANY streams at once (a live server's staging buffers fill in the same round): one wait, one launch,
+// no per-stream copies. Streams that cannot be compacted (nothing consumed yet) are left to push_enqueue's own check.
+static int compact_streams(opv_ctx* c, const std::vector<int>& which) {
+    HIPCHK(hipStreamSynchronize(c->copy_stream));         // copies enqueued earlier land first
+    if (int r = c->refresh()) return r;
+    CompactItem* items = nullptr;
+    PushPair* pairs = nullptr;
+    if (int r = bulk_table(c, (size_t)c->n_streams, &items, &pairs)) return r;
+    uint32_t m = 0;
+    for (int s : which) {
+        HostStream& h = c->hs[s];
+        OpvStream& st = c->mirror[s];
+        const uint64_t keep = st.origin >= 16 ? ((st.origin - 16) & ~3ull) : 0;
+        if (keep == 0 || !h.d_iq_owned) continue;
+        const uint64_t len = h.n_avail - keep;
+        if (!h.d_iq_alt) HIPCHK(hipMalloc(&h.d_iq_alt, h.iq_cap * 4 + 16384));
+        items[m++] = {(const int*)(h.d_iq_owned + 2 * keep), (int*)h.d_iq_alt, (uint32_t)len, (uint32_t)s, keep};
+        std::swap(h.d_iq_owned, h.d_iq_alt);
+        h.d_iq = h.d_iq_owned;
+        h.n_avail -= keep;
+        h.last_round_avail = h.last_round_avail > keep ? h.last_round_avail - keep : 0;
+        h.dirty = true;                                    // (iq and n_avail reach the device with the next round's inputs)
+        st.iq = h.d_iq;
+        st.origin -= keep;
+        st.n_avail -= keep;
+        st.iq_base += keep;
+    }
+    if (m) {
+        void* d_items = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&d_items, items, 0));
+        const uint32_t slices = m >= 1024 ? 1 : (1024 + m - 1) / m;
+        uint32_t grid = m * slices;
+        if (grid > 2048) grid = 2048;
+        k_compact<<<grid, 256, 0, c->stream>>>(c->d_streams, (const CompactItem*)d_items, m, slices);   // in stream order before the next kernels
+        HIPCHK(hipGetLastError());
+    }
+    return OPV_OK;
+}
+
+struct DeferredCopy { void* dst; const void* src; size_t bytes; };
+static int push_deferred(opv_ctx* c, const std::vector<DeferredCopy>& copies);
+
+static int push_enqueue(opv_ctx* c, int s, const int16_t* iq, size_t n, std::vector<DeferredCopy>* defer = nullptr) {
     if (int r = check_stream(c, s)) return r;
     HostStream& h = c->hs[s];
     if (h.attached) return fail(OPV_ESTATE, "stream has an attached device capture");
@@ -455,6 +587,10 @@ static int push_enqueue(opv_ctx* c, int s, const int16_t* iq, size_t n) {
     if (n == 0) return OPV_OK;
     if (!iq) return fail(OPV_EINVAL, "null IQ pointer");
     if (h.n_avail + n > c->cfg.max_samples) {
+        if (defer && !defer->empty()) {                // blocks of this batch not yet under way (one of them may be this stream's) go first
+            if (int r = push_deferred(c, *defer)) return r;
+            defer->clear();
+        }
         HIPCHK(hipStreamSynchronize(c->copy_stream));  // copies enqueued earlier in this batch land first
         if (int r = compact_stream(c, s)) return r;
         if (h.n_avail + n > c->cfg.max_samples)
@@ -469,9 +605,46 @@ static int push_enqueue(opv_ctx* c, int s, const int16_t* iq, size_t n) {
     // On the copy stream: the kernels of an opv_process still in flight only read samples below the
     // n_avail they were launched with, so new samples land behind them while they run (H2D over
     // PCIe overlaps compute).
-    HIPCHK(hipMemcpyAsync(h.d_iq_owned + 2 * h.n_avail, iq, n * 4, hipMemcpyHostToDevice, c->copy_stream));
+    if (defer) defer->push_back({h.d_iq_owned + 2 * h.n_avail, iq, n * 4});   // (opv_push_iq_batch moves its blocks together)
+    else HIPCHK(hipMemcpyAsync(h.d_iq_owned + 2 * h.n_avail, iq, n * 4, hipMemcpyHostToDevice, c->copy_stream));
     h.n_avail += n;
     h.dirty = true;
+    return OPV_OK;
+}
+
+// The deferred copies of one batch. Blocks in pinned (device-visible) host memory go through ONE gather kernel on the copy
+// stream; anything else - pageable memory, a source that is not 4-byte aligned - takes hipMemcpyAsync as before.
+static int push_deferred(opv_ctx* c, const std::vector<DeferredCopy>& copies) {
+    if (copies.empty()) return OPV_OK;
+    CompactItem* items = nullptr;
+    PushPair* pairs = nullptr;
+    uint32_t m = 0;
+    const bool try_gather = copies.size() >= 2 && !std::getenv("OPV_PUSH_NO_GATHER");   // (test hook: the per-stream copies)
+    if (try_gather)
+        if (int r = bulk_table(c, copies.size() > (size_t)c->n_streams ? copies.size() : (size_t)c->n_streams, &items, &pairs)) return r;
+    for (const DeferredCopy& k : copies) {
+        bool gathered = false;
+        if (try_gather && ((uintptr_t)k.src & 3u) == 0 && k.bytes < (1ull << 32)) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, k.src) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+                const uint32_t wide = (((uintptr_t)at.devicePointer | (uintptr_t)k.dst) & 15u) == 0 ? 1u : 0u;
+                pairs[m++] = {at.devicePointer, k.dst, (uint32_t)k.bytes, wide};
+                gathered = true;
+            } else {
+                (void)hipGetLastError();                   // (pageable memory: "invalid value" - not an error of ours)
+            }
+        }
+        if (!gathered) HIPCHK(hipMemcpyAsync(k.dst, k.src, k.bytes, hipMemcpyHostToDevice, c->copy_stream));
+    }
+    if (m) {
+        void* d_pairs = nullptr;
+        HIPCHK(hipHostGetDevicePointer(&d_pairs, pairs, 0));
+        const uint32_t slices = m >= 1024 ? 1 : (1024 + m - 1) / m;   // >= 1024 work items: enough 16-byte loads in flight for the link
+        uint32_t grid = m * slices;
+        if (grid > 1024) grid = 1024;
+        k_push_gather<<<grid, 256, 0, c->copy_stream>>>((const PushPair*)d_pairs, m, slices);
+        HIPCHK(hipGetLastError());
+    }
     return OPV_OK;
 }
 
@@ -489,10 +662,23 @@ extern "C" int opv_push_iq_batch(opv_ctx* c, int count, const int* streams, cons
     if (!c) return fail(OPV_EINVAL, "null context");
     if (count < 0 || (count > 0 && (!streams || !iq || !n_samples))) return fail(OPV_EINVAL, "opv_push_iq_batch: bad arguments");
     HIPCHK(hipSetDevice(c->cfg.device));
+    // staging buffers that would overflow are compacted together first (a live server's streams fill in the same round)
+    std::vector<int> full;
+    for (int i = 0; i < count; ++i) {
+        const int s = streams[i];
+        if (s < 0 || s >= c->n_streams) continue;          // (reported by push_enqueue below, at its place in the order)
+        const HostStream& h = c->hs[s];
+        if (!h.attached && !h.eof && n_samples[i] && h.n_avail + n_samples[i] > c->cfg.max_samples) full.push_back(s);
+    }
+    if (full.size() >= 2)
+        if (int r = compact_streams(c, full)) return r;
+    std::vector<DeferredCopy> copies;
+    copies.reserve((size_t)count);
     int rc = OPV_OK;
-    for (int i = 0; i < count && rc == OPV_OK; ++i) rc = push_enqueue(c, streams[i], iq[i], n_samples[i]);
+    for (int i = 0; i < count && rc == OPV_OK; ++i) rc = push_enqueue(c, streams[i], iq[i], n_samples[i], &copies);
+    const int rc2 = push_deferred(c, copies);              // (streams before an error have been pushed)
     HIPCHK(hipStreamSynchronize(c->copy_stream));  // one wait for all copies; the buffers are the caller's again
-    return rc;
+    return rc != OPV_OK ? rc : rc2;
 }
 
 extern "C" int opv_flush(opv_ctx* c, int s) {

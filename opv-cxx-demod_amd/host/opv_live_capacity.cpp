@@ -10,9 +10,11 @@
 //
 //   opv-live-capacity <n_streams> [rounds (120)] [warmup (6)] [device (0)]
 //
-// Every stream carries the same clean BERT capture (host modulator, bit-identical to `opv-mod -S W5NYV -B <rounds + warmup + 1>`);
-// the N copies still cross PCIe separately and are demodulated separately. Checked: after the first round every round releases
-// exactly one frame per stream, equal to the transmitted one.
+// The signal is ONE clean BERT run of N + rounds + warmup + 1 frames (the device transmit chain, bit-identical to `opv-mod -S W5NYV
+// -B ...`, brought back into pinned host memory); stream k listens to it from frame k on. So in every round every stream's
+// chunk lies at its own host addresses - N x 347 KB of distinct pinned memory cross PCIe per round, nothing a device cache
+// could serve twice (with one shared chunk the gather kernel "moved" 1.8 TB/s: L2 hits) - and every stream decodes its own
+// frame sequence. Checked: after the first round every round releases exactly one frame per stream, equal to the transmitted one.
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -36,16 +38,16 @@ int main(int argc, char** argv) {
     const int total = rounds + warm;
     const size_t chunk = OPV_CHUNK_SAMPLES;
 
-    // the signal: total + 1 frames (+ the modulator's 100 silent symbols), in pinned memory
-    std::vector<uint8_t> frames((size_t)(total + 1) * OPV_FRAME_BYTES);
-    opv_tx_bert_frames("W5NYV", 0xBBAADD, 0, (size_t)total + 1, frames.data());
-    const size_t n_all = opv_tx_modulated_samples((size_t)total + 1);
+    // the signal: N + total + 1 frames (+ the modulator's 100 silent symbols), in pinned memory
+    const size_t n_frames = (size_t)N + (size_t)total + 1;
+    std::vector<uint8_t> frames(n_frames * OPV_FRAME_BYTES);
+    opv_tx_bert_frames("W5NYV", 0xBBAADD, 0, n_frames, frames.data());
+    const size_t n_all = opv_tx_modulated_samples(n_frames);
     int16_t* iq = nullptr;
     if (hipSetDevice(device) != hipSuccess || hipHostMalloc((void**)&iq, n_all * 4, hipHostMallocDefault) != hipSuccess) {
         fprintf(stderr, "opv-live-capacity: no pinned host memory / no HIP device\n");
         return 2;
     }
-    opv_tx_modulate(frames.data(), (size_t)total + 1, iq);
 
     opv_cfg cfg;
     memset(&cfg, 0, sizeof cfg);
@@ -56,6 +58,7 @@ int main(int argc, char** argv) {
     cfg.max_samples = 4 * chunk + 65536;               // a live server's staging buffer: a few chunks per stream
     opv_ctx* ctx = nullptr;
     if (opv_create(&ctx, N, &cfg) < 0) { fprintf(stderr, "opv-live-capacity: %s\n", opv_last_error()); return 2; }
+    if (opv_tx_modulate_device_to_host(ctx, frames.data(), n_frames, iq) < 0) { fprintf(stderr, "opv-live-capacity: %s\n", opv_last_error()); return 2; }
 
     std::vector<int> ids(N);
     std::vector<const int16_t*> ptrs(N);
@@ -69,7 +72,7 @@ int main(int argc, char** argv) {
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     for (int r = 0; r < total; ++r) {
-        for (int k = 0; k < N; ++k) ptrs[k] = iq + 2 * (size_t)r * chunk;
+        for (int k = 0; k < N; ++k) ptrs[k] = iq + 2 * ((size_t)r + (size_t)k) * chunk;    // stream k is k frames into the run
         const auto t0 = clk::now();
         if (opv_push_iq_batch(ctx, N, ids.data(), ptrs.data(), lens.data()) < 0) { fprintf(stderr, "push: %s\n", opv_last_error()); return 2; }
         const auto t1 = clk::now();
@@ -80,8 +83,8 @@ int main(int argc, char** argv) {
             const long g = opv_pop_frames(ctx, k, out, 4, meta);
             if (g < 0) { fprintf(stderr, "pop: %s\n", opv_last_error()); return 2; }
             for (long f = 0; f < g; ++f) {
-                const size_t idx = next[k]++;
-                if (idx > (size_t)total || memcmp(out + f * OPV_FRAME_BYTES, frames.data() + idx * OPV_FRAME_BYTES, OPV_FRAME_BYTES) != 0) ++wrong;
+                const size_t idx = (size_t)k + next[k]++;
+                if (idx >= n_frames || memcmp(out + f * OPV_FRAME_BYTES, frames.data() + idx * OPV_FRAME_BYTES, OPV_FRAME_BYTES) != 0) ++wrong;
                 if (meta[f].viterbi_metric != 0) ++imperfect;
             }
             got_round += g;

@@ -1660,6 +1660,77 @@ def test_push_batch_and_pooled_pops(amd, oracle, iq10):
     d.close()
 
 
+@pytest.mark.parametrize("gather", [True, False])
+def test_push_batch_from_pinned_memory_and_batched_compaction(amd, oracle, iq10, iq100, gather, monkeypatch):
+    """The serving path's bulk moves (csrc/opv_capi.hip: k_push_gather, k_compact). Blocks that lie in PINNED host memory cross
+    PCIe through one gather kernel per opv_push_iq_batch (read through their device-visible addresses) instead of one copy per
+    stream, and staging buffers that fill in the same round are compacted by one launch. 14 streams with a staging buffer of
+    about three chunks (so every stream compacts every few rounds, most of them together), blocks of ragged sizes: 16-byte
+    aligned ones, ones starting one, two or three samples into a quad (4-byte moves), lengths that are no multiple of four
+    samples, a stream with two blocks in one batch, a block from PAGEABLE memory in the same batch (takes hipMemcpyAsync), and
+    a stream whose second block of a batch forces its own compaction. gather=False (OPV_PUSH_NO_GATHER) runs the same rounds
+    over the per-stream copies. Every stream's frames, metrics, sync positions, tracker lines and soft symbols equal the oracle's."""
+    import torch
+    if not gather:
+        monkeypatch.setenv("OPV_PUSH_NO_GATHER", "1")
+    caps = [impair(iq100[: 2 * 86720 * 30], amp=2500.0, f0_hz=-1500.0 + 230.0 * k, ebn0_db=15.0, seed=70 + k) for k in range(12)]
+    caps += [iq100[: 2 * 86720 * 30].copy(), iq10.copy()]
+    S = len(caps)
+    pinned = []
+    for k, x in enumerate(caps):                                   # every capture in its own pinned buffer, at a sample offset 0..3
+        t = torch.empty(x.size + 8, dtype=torch.int16).pin_memory()
+        v = t.numpy()[2 * (k % 4): 2 * (k % 4) + x.size]
+        v[:] = x
+        pinned.append((t, v))
+    d = amd.Demod(S, max_samples=3 * 86720 + 20000, streaming=True)
+    sizes = [86720, 40001, 86720, 130002, 86723, 4096]
+    at = [0] * S
+    frames = [[] for _ in range(S)]
+    events = [[] for _ in range(S)]
+    soft = [[] for _ in range(S)]
+    r = 0
+    while any(a < c.size // 2 for a, c in zip(at, caps)):
+        ids, blks = [], []
+        for k in range(S):
+            for part in range(2 if k == 5 else 1):                 # stream 5: two blocks per batch
+                n = min(sizes[(r + k + part) % len(sizes)] // (2 if k == 5 else 1), caps[k].size // 2 - at[k])
+                if n > 0:
+                    src = pinned[k][1] if not (k == 7 and r % 3 == 1) else caps[k]       # stream 7: every third round from pageable memory
+                    ids.append(k); blks.append(src[2 * at[k]: 2 * (at[k] + n)]); at[k] += n
+        d.push_batch(ids, blks)
+        d.process()
+        for k in range(S):
+            fr, meta = d.pop_frames(k)
+            frames[k].append((fr, meta))
+            events[k].append(d.pop_events(k))
+            st = d.state(k)
+            done = sum(len(x) for x in soft[k])
+            if st.total_symbols > done:
+                soft[k].append(d.soft(k, first=done, cap=int(st.total_symbols - done)))
+        r += 1
+    for k in range(S):
+        d.flush(k)
+    d.process()
+    for k in range(S):
+        fr, meta = d.pop_frames(k)
+        frames[k].append((fr, meta))
+        events[k].append(d.pop_events(k))
+        st = d.state(k)
+        done = sum(len(x) for x in soft[k])
+        if st.total_symbols > done:
+            soft[k].append(d.soft(k, first=done, cap=int(st.total_symbols - done)))
+        exp = oracle.receive(caps[k], streaming=True)
+        got_fr = np.concatenate([f for f, _ in frames[k]])
+        got_meta = np.concatenate([m for _, m in frames[k]])
+        assert np.array_equal(got_fr, exp["frames"]), (k, len(got_fr), len(exp["frames"]))
+        assert np.array_equal(got_meta["viterbi_metric"], exp["metrics"]) and np.array_equal(got_meta["release_symbol"], exp["frame_sym"]), k
+        events_match(amd, np.concatenate(events[k]), exp["events"])
+        assert st.total_symbols == exp["n_soft"], k
+        a, _ = soft_err(np.concatenate(soft[k]), exp["soft"])
+        assert a < SOFT_TIGHT, (k, a)
+    d.close()
+
+
 def test_device_clock_error_tool(amd, oracle, iq10):
     """the device channel chain with a sample-clock error. opv_resample_device is bit-identical
     to the numpy model the CPU-side tests use; modulate -> resample -> channel -> receive stays in HBM and the
