@@ -141,7 +141,13 @@ int main(int argc, char** argv) {
     constexpr size_t kRead = 16384;                       // opv-modem's read size (src/opv-modem.cpp:734,753)
     constexpr size_t kDgram = 65536;                      // a UDP datagram is taken whole (<= 65507 bytes of payload)
     constexpr size_t kRound = 1u << 20;                   // at most this much per stream and poll round (0.12 s of IQ)
-    std::vector<unsigned char> bufs((size_t)S * (kRound + kDgram + 4));   // one buffer per stream: a poll round is ONE batched push
+    // one buffer per stream, 16-byte aligned, in PINNED host memory: a poll round is ONE batched push, and opv_push_iq_batch
+    // moves blocks that lie in pinned memory with one gather kernel at the link's rate instead of one copy per stream
+    constexpr size_t kStride = kRound + kDgram + 16;
+    unsigned char* bufs = nullptr;
+    bool bufs_pinned = hipHostMalloc((void**)&bufs, (size_t)S * kStride, hipHostMallocPortable) == hipSuccess;
+    if (!bufs_pinned) bufs = (unsigned char*)malloc((size_t)S * kStride);     // (pageable works too: per-stream copies)
+    if (!bufs) { fprintf(stderr, "opv-rx-bridge: out of host memory\n"); return 2; }
     std::vector<int> pending_flush;
     std::vector<std::vector<int>> ids(D);
     std::vector<std::vector<const int16_t*>> ptrs(D);
@@ -176,7 +182,7 @@ int main(int argc, char** argv) {
             if (!(pfd[k].revents & (POLLIN | POLLHUP))) continue;
             // everything the source has ready goes into this round (reads of 16 KB like the reference's loop, a
             // datagram at a time for UDP): one push + one opv_process per poll round, however fast the data arrives
-            unsigned char* buf = bufs.data() + (size_t)k * (kRound + kDgram + 4);
+            unsigned char* buf = bufs + (size_t)k * kStride;
             memcpy(buf, in[k].carry, in[k].ncarry);
             size_t have = in[k].ncarry;
             bool ended = false;
@@ -270,6 +276,8 @@ int main(int argc, char** argv) {
         for (void* c : comms) opv_comm_destroy(c);
     }
     for (opv_ctx* c : ctxs) opv_destroy(c);
+    if (bufs_pinned) (void)hipHostFree(bufs);
+    else free(bufs);
     close(sock);
     return rc;
 }

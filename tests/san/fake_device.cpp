@@ -241,8 +241,10 @@ long opv_tx_modulate_device_to_host(opv_ctx* c, const uint8_t* frames134, size_t
     return 0;
 }
 
-// ---- the four HIP runtime calls host/opv_rx_bridge.cpp makes itself
+// ---- the HIP runtime calls host/opv_rx_bridge.cpp makes itself
 int hipSetDevice(int) { return 0; }
+int hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+int hipHostFree(void* p) { free(p); return 0; }
 int hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 int hipFree(void* p) { free(p); return 0; }
 int hipMemcpy(void* dst, const void* src, size_t n, int) { memcpy(dst, src, n); return 0; }

@@ -111,6 +111,42 @@ def symmetric_openings(seed, n_streams=208):
     return caps
 
 
+def offset_opening(seed, k):
+    """ONE opening for estimate_offset, a function of (seed, k) alone (so that single finds of scripts/experiments/near_tie_hunt.py
+    can be regenerated): a random start inside a 3-frame BERT run, carrier offset within and beyond the search span, level,
+    Eb/N0 3 .. 22 dB, 20 000 .. 45 000 samples."""
+    from oracle_lib import Oracle, impair
+    global _OPENING_BASE
+    try:
+        base = _OPENING_BASE
+    except NameError:
+        o = Oracle()
+        base = _OPENING_BASE = o.modulate(o.bert_frames(3, "NT", first=4242))
+    rng = np.random.default_rng([int(seed), int(k)])
+    n = int(rng.choice([20000, 30000, 39999, 40000, 40001, 45000]))
+    at = int(rng.integers(0, base.size // 2 - n - 1))
+    x = impair(base[2 * at: 2 * (at + n)], amp=float(rng.uniform(300, 12000)), f0_hz=float(rng.uniform(-2200, 2200)),
+               ebn0_db=float(rng.uniform(3, 22)), seed=int(rng.integers(1, 2 ** 31)))
+    return np.ascontiguousarray(x)
+
+
+def near_tie_class(e, rel=1e-11):
+    """Does the strict-'>' scan of estimate_offset over these 134 energies (121 coarse, then 13 fine around the coarse winner) meet
+    a NEAR tie - a contender within `rel` of the best energy in play that is not equal to it? Returns "coarse", "fine" or ""."""
+    e = np.asarray(e)
+    c = e[:121]
+    top = c.max()
+    near = c[(c >= top * (1 - rel)) & (c != top)]
+    if near.size:
+        return "coarse"
+    best = int(np.argmax(c))                       # first maximum
+    f = np.delete(e[121:134], 6)                   # (entry 6 of the fine pass repeats the coarse winner's offset)
+    top2 = max(top, f.max())
+    pool = np.concatenate([[top], f])
+    near = pool[(pool >= top2 * (1 - rel)) & (pool != top2)]
+    return "fine" if near.size else ""
+
+
 def oracle_offset_chunk(caps):
     from oracle_lib import Oracle
     o = Oracle()
