@@ -129,20 +129,23 @@ def live_capacity(dev_index):
     streams at once: how many live streams ONE context serves in real time. bin/opv-live-capacity (host/opv_live_capacity.cpp, a
     C++ caller of the C ABI like opv-rx-bridge) runs 120 serving rounds - one 86 720-sample chunk per stream pushed from pinned host
     memory over PCIe (every stream's chunk at its own host addresses: N x 347 KB of distinct memory per round), opv_process, every
-    stream's frames popped and compared with what was sent - and reports the round-time distribution; the
-    capacity is the largest N probed whose p99 round stays under the 40 ms of signal a round consumes. Doubling, then bisection
-    to 256 streams."""
+    stream's frames popped and compared with what was sent - and reports the round-time distribution; the capacity is the largest N
+    probed whose p99 round stays under the 40 ms of signal a round consumes. Doubling, then bisection to 256 streams - for the serial
+    loop (push, process, pop) and, upwards from there, for the double-buffered one (opv_push_iq_batch_async: round r + 1 crosses PCIe
+    while round r is processed and popped)."""
     exe = ROOT / "opv-cxx-demod_amd" / "bin" / "opv-live-capacity"
     if not exe.exists():
         return None
     probes = {}
 
-    def probe(n):
-        if n not in probes:
-            p = subprocess.run([str(exe), str(n), "120", "6", str(dev_index)], capture_output=True, text=True, timeout=180)
+    def probe(n, pipelined=False):
+        key = (n, pipelined)
+        if key not in probes:
+            p = subprocess.run([str(exe), str(n), "120", "6", str(dev_index)] + (["--pipelined"] if pipelined else []),
+                               capture_output=True, text=True, timeout=240)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-            probes[n] = json.loads(line[-1]) if p.returncode == 0 and line else {"streams": n, "error": (p.stderr or p.stdout)[-200:], "rc": p.returncode}
-        r = probes[n]
+            probes[key] = json.loads(line[-1]) if p.returncode == 0 and line else {"streams": n, "pipelined": pipelined, "error": (p.stderr or p.stdout)[-200:], "rc": p.returncode}
+        r = probes[key]
         return "error" not in r and r["round_ms_p99"] < 40.0 and r["frames_wrong"] == 0
     lo, hi = 0, None
     n = 1024
@@ -161,9 +164,18 @@ def live_capacity(dev_index):
             lo = mid
         else:
             hi = mid
-    best = probes.get(lo)
+    plo = 0
+    if lo:
+        n = lo
+        while n <= 16384 and n - lo <= 2048 and probe(n, True):     # upwards from the serial figure, 256 streams at a time
+            plo = n
+            n += 256
+    best, pbest = probes.get((lo, False)), probes.get((plo, True))
     return {"streams": lo, "round_ms_p99": best["round_ms_p99"] if best else None, "round_ms_p50": best["round_ms_p50"] if best else None,
             "Msamples/s_sustained": round(lo * 2.168, 1), "first_n_over_40ms": hi,
+            "pipelined": {"streams": plo, "round_ms_p99": pbest["round_ms_p99"] if pbest else None, "round_ms_p50": pbest["round_ms_p50"] if pbest else None,
+                          "Msamples/s_sustained": round(plo * 2.168, 1),
+                          "what": "the same rounds with opv_push_iq_batch_async: the next round's chunks cross PCIe while this round is processed and popped"},
             "probes": [probes[k] for k in sorted(probes)],
             "what": "largest probed N with p99 round < 40 ms over 120 rounds: one 86720-sample chunk per stream from pinned host memory "
                     "(opv_push_iq_batch), opv_process + opv_sync, opv_pop_frames of every stream (bin/opv-live-capacity)"}

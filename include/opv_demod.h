@@ -21,7 +21,8 @@ extern "C" {
 #endif
 
 #define OPV_ABI_VERSION 6   /* 6: offset-search near-ties are decided with the HOST's libm (opv_offset_ties_on_host), one host wait in the round
-                               in which a stream's search runs;
+                               in which a stream's search runs; + opv_push_iq_batch_async / opv_push_wait; opv_push_iq_batch moves blocks in
+                               pinned host memory with one gather kernel;
                                5: opv_set_frontend takes 16 (sixteen streams per wavefront; automatic from 8193 streams) and answers OPV_EINVAL to
                                the comparison mappings -1 / -2 unless built with them; opv_create refuses non-finite -o / -a / -p values;
                                an idle opv_process launches nothing for callers that never pop (zero-copy path);
@@ -145,6 +146,15 @@ int opv_push_iq(opv_ctx* ctx, int stream, const int16_t* iq_interleaved, size_t 
  * blocks take one hipMemcpyAsync each, as opv_push_iq does. Results do not depend on the route. */
 int opv_push_iq_batch(opv_ctx* ctx, int count, const int* streams, const int16_t* const* iq_interleaved,
                       const size_t* n_samples);
+/* The same without the wait at its end, for a server that double-buffers its host memory: returns once the moves are ENQUEUED; the
+ * blocks must stay valid and unchanged until opv_push_wait returns (every other opv_push_* call and opv_reset_stream wait first
+ * by themselves). opv_process may be called in between - its kernels queue behind every move enqueued so far, on the device - so
+ * that round r + 1 crosses PCIe while the kernels of round r run and the frames of round r are popped:
+ *     opv_push_iq_batch_async(r = 0);  loop: opv_push_wait; opv_process; opv_push_iq_batch_async(r + 1); opv_sync; opv_pop_frames...
+ * A serving round then costs max(PCIe, kernels + pops) instead of their sum (bin/opv-live-capacity --pipelined). */
+int opv_push_iq_batch_async(opv_ctx* ctx, int count, const int* streams, const int16_t* const* iq_interleaved,
+                            const size_t* n_samples);
+int opv_push_wait(opv_ctx* ctx);
 /* EOF on a stream: enables the tail processing of :1088-1113 (streaming) or the single
  * whole-capture demodulate of :1166-1173 (batch) at the next opv_process. */
 int opv_flush(opv_ctx* ctx, int stream);

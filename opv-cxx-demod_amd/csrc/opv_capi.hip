@@ -234,6 +234,10 @@ struct opv_ctx {
     // opv_push_iq_batch: the table of the gather kernel / of the batched compaction, in pinned memory (the kernels read it in place)
     void* h_bulk_tab = nullptr;
     size_t bulk_tab_bytes = 0;
+    // opv_push_iq_batch_async: moves enqueued on the copy stream that no host wait has covered yet; opv_process orders its kernels
+    // behind push_ev on the device, every other push entry point waits on the host first
+    bool push_pending = false;
+    hipEvent_t push_ev = nullptr;
     uint64_t cap_soft = 0;
     uint32_t cap_frames = 0, cap_events = 0, cap_chunks = 0;
     bool mirror_valid = false;
@@ -466,6 +470,7 @@ extern "C" void opv_destroy(opv_ctx* c) {
     if (c->h_stall) (void)hipHostFree(c->h_stall);
     if (c->h_tie_list) (void)hipHostFree(c->h_tie_list);
     if (c->h_bulk_tab) (void)hipHostFree(c->h_bulk_tab);
+    if (c->push_ev) (void)hipEventDestroy(c->push_ev);
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto& h : c->hs) {
@@ -648,9 +653,25 @@ static int push_deferred(opv_ctx* c, const std::vector<DeferredCopy>& copies) {
     return OPV_OK;
 }
 
+// moves of an opv_push_iq_batch_async still under way: every other push entry point (and reset / destroy) waits for them first
+static int settle_pushes(opv_ctx* c) {
+    if (c->push_pending) {
+        HIPCHK(hipStreamSynchronize(c->copy_stream));
+        c->push_pending = false;
+    }
+    return OPV_OK;
+}
+
+extern "C" int opv_push_wait(opv_ctx* c) {
+    if (!c) return fail(OPV_EINVAL, "null context");
+    HIPCHK(hipSetDevice(c->cfg.device));
+    return settle_pushes(c);
+}
+
 extern "C" int opv_push_iq(opv_ctx* c, int s, const int16_t* iq, size_t n) {
     if (!c) return fail(OPV_EINVAL, "null context");
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (int r = settle_pushes(c)) return r;
     if (int r = push_enqueue(c, s, iq, n)) return r;
     // The caller keeps ownership of `iq`: the copy must have left the host buffer before we return,
     // which is a wait for THIS copy only, not for the kernels.
@@ -658,10 +679,21 @@ extern "C" int opv_push_iq(opv_ctx* c, int s, const int16_t* iq, size_t n) {
     return OPV_OK;
 }
 
+static int push_batch(opv_ctx* c, int count, const int* streams, const int16_t* const* iq, const size_t* n_samples, bool wait);
+
 extern "C" int opv_push_iq_batch(opv_ctx* c, int count, const int* streams, const int16_t* const* iq, const size_t* n_samples) {
+    return push_batch(c, count, streams, iq, n_samples, true);
+}
+
+extern "C" int opv_push_iq_batch_async(opv_ctx* c, int count, const int* streams, const int16_t* const* iq, const size_t* n_samples) {
+    return push_batch(c, count, streams, iq, n_samples, false);
+}
+
+static int push_batch(opv_ctx* c, int count, const int* streams, const int16_t* const* iq, const size_t* n_samples, bool wait) {
     if (!c) return fail(OPV_EINVAL, "null context");
     if (count < 0 || (count > 0 && (!streams || !iq || !n_samples))) return fail(OPV_EINVAL, "opv_push_iq_batch: bad arguments");
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (int r = settle_pushes(c)) return r;                // (the table of an earlier asynchronous batch may still be read)
     // staging buffers that would overflow are compacted together first (a live server's streams fill in the same round)
     std::vector<int> full;
     for (int i = 0; i < count; ++i) {
@@ -677,7 +709,13 @@ extern "C" int opv_push_iq_batch(opv_ctx* c, int count, const int* streams, cons
     int rc = OPV_OK;
     for (int i = 0; i < count && rc == OPV_OK; ++i) rc = push_enqueue(c, streams[i], iq[i], n_samples[i], &copies);
     const int rc2 = push_deferred(c, copies);              // (streams before an error have been pushed)
-    HIPCHK(hipStreamSynchronize(c->copy_stream));  // one wait for all copies; the buffers are the caller's again
+    if (wait || rc != OPV_OK || rc2 != OPV_OK) {
+        HIPCHK(hipStreamSynchronize(c->copy_stream));      // one wait for all copies; the buffers are the caller's again
+    } else {
+        if (!c->push_ev) HIPCHK(hipEventCreateWithFlags(&c->push_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->push_ev, c->copy_stream)); // opv_process orders its kernels behind this; opv_push_wait waits on the host
+        c->push_pending = true;
+    }
     return rc != OPV_OK ? rc : rc2;
 }
 
@@ -777,6 +815,8 @@ extern "C" int opv_process(opv_ctx* c) {
     c->mirror_valid = false;
     c->maybe_stalled = true;
     c->h_stall[slot] = 0;          // (a straggler of round_no - kInSlots could still set it: then one idle round too many, never one too few)
+    // samples of an asynchronous batch still crossing PCIe: this round's kernels read them, so they queue behind the moves (on the device)
+    if (c->push_pending) HIPCHK(hipStreamWaitEvent(c->stream, c->push_ev, 0));
     // pinned -> device, in stream order behind the previous round's kernels; no host wait
     HIPCHK(hipMemcpyAsync(c->d_in, in, sizeof(StreamIn) * S, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->in_ev[slot], c->stream));
@@ -876,6 +916,7 @@ extern "C" int opv_reset_stream(opv_ctx* c, int s) {
     if (!c) return fail(OPV_EINVAL, "null context");
     if (s != -1) { if (int r = check_stream(c, s)) return r; }
     HIPCHK(hipSetDevice(c->cfg.device));
+    if (int r = settle_pushes(c)) return r;
     HIPCHK(hipStreamSynchronize(c->stream));
     const int lo = (s == -1) ? 0 : s, hi = (s == -1) ? c->n_streams : s + 1;
     for (int i = lo; i < hi; ++i) {

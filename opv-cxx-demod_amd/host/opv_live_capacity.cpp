@@ -8,7 +8,11 @@
 // largest N whose p99 stays under 40 ms (extras.live_capacity). No kernel is specific to this tool: it is a caller of
 // include/opv_demod.h like opv-rx-bridge, without sockets so that the number is the library's.
 //
-//   opv-live-capacity <n_streams> [rounds (120)] [warmup (6)] [device (0)]
+//   opv-live-capacity <n_streams> [rounds (120)] [warmup (6)] [device (0)] [--pipelined]
+//     --pipelined   the double-buffered server: opv_push_iq_batch_async of round r + 1 is enqueued right behind opv_process of
+//                   round r, so the chunks of the next round cross PCIe while this round's kernels run and its frames are
+//                   popped; a round then costs max(PCIe, kernels + pops). Reported per round: the time from one opv_push_wait
+//                   to the next (steady-state period); a chunk's frames surface one round later than in the serial loop.
 //
 // The signal is ONE clean BERT run of N + rounds + warmup + 1 frames (the device transmit chain, bit-identical to `opv-mod -S W5NYV
 // -B ...`, brought back into pinned host memory); stream k listens to it from frame k on. So in every round every stream's
@@ -32,6 +36,8 @@ int main(int argc, char** argv) {
         fprintf(stderr, "Usage: %s <n_streams> [rounds] [warmup] [device]\n", argv[0]);
         return 2;
     }
+    bool pipelined = false;
+    if (argc > 2 && !strcmp(argv[argc - 1], "--pipelined")) { pipelined = true; --argc; }
     const int N = atoi(argv[1]);
     const int rounds = argc > 2 ? atoi(argv[2]) : 120, warm = argc > 3 ? atoi(argv[3]) : 6, device = argc > 4 ? atoi(argv[4]) : 0;
     if (N < 1 || rounds < 1 || warm < 1) { fprintf(stderr, "opv-live-capacity: bad arguments\n"); return 2; }
@@ -71,12 +77,26 @@ int main(int argc, char** argv) {
     std::vector<size_t> next(N, 0);                     // per stream: the number of the next frame it owes
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto set_ptrs = [&](int r) { for (int k = 0; k < N; ++k) ptrs[k] = iq + 2 * ((size_t)r + (size_t)k) * chunk; };   // stream k is k frames into the run
+    if (pipelined) {
+        set_ptrs(0);
+        if (opv_push_iq_batch_async(ctx, N, ids.data(), ptrs.data(), lens.data()) < 0) { fprintf(stderr, "push: %s\n", opv_last_error()); return 2; }
+    }
     for (int r = 0; r < total; ++r) {
-        for (int k = 0; k < N; ++k) ptrs[k] = iq + 2 * ((size_t)r + (size_t)k) * chunk;    // stream k is k frames into the run
         const auto t0 = clk::now();
-        if (opv_push_iq_batch(ctx, N, ids.data(), ptrs.data(), lens.data()) < 0) { fprintf(stderr, "push: %s\n", opv_last_error()); return 2; }
+        if (pipelined) {
+            if (opv_push_wait(ctx) < 0) { fprintf(stderr, "push wait: %s\n", opv_last_error()); return 2; }   // round r's chunks have landed
+        } else {
+            set_ptrs(r);
+            if (opv_push_iq_batch(ctx, N, ids.data(), ptrs.data(), lens.data()) < 0) { fprintf(stderr, "push: %s\n", opv_last_error()); return 2; }
+        }
         const auto t1 = clk::now();
-        if (opv_process(ctx) < 0 || opv_sync(ctx) < 0) { fprintf(stderr, "process: %s\n", opv_last_error()); return 2; }
+        if (opv_process(ctx) < 0) { fprintf(stderr, "process: %s\n", opv_last_error()); return 2; }
+        if (pipelined && r + 1 < total) {                 // round r + 1 starts crossing PCIe behind round r's launches
+            set_ptrs(r + 1);
+            if (opv_push_iq_batch_async(ctx, N, ids.data(), ptrs.data(), lens.data()) < 0) { fprintf(stderr, "push: %s\n", opv_last_error()); return 2; }
+        }
+        if (opv_sync(ctx) < 0) { fprintf(stderr, "process: %s\n", opv_last_error()); return 2; }
         const auto t2 = clk::now();
         long got_round = 0;
         for (int k = 0; k < N; ++k) {
@@ -104,10 +124,10 @@ int main(int argc, char** argv) {
         const size_t i = (size_t)(p * (double)(v.size() - 1) + 0.5);
         return v[i < v.size() ? i : v.size() - 1];
     };
-    printf("{\"streams\": %d, \"rounds\": %d, \"signal_ms_per_round\": 40.0, \"round_ms_p50\": %.3f, \"round_ms_p99\": %.3f, \"round_ms_max\": %.3f, "
+    printf("{\"streams\": %d, \"pipelined\": %s, \"rounds\": %d, \"signal_ms_per_round\": 40.0, \"round_ms_p50\": %.3f, \"round_ms_p99\": %.3f, \"round_ms_max\": %.3f, "
            "\"push_ms_p50\": %.3f, \"process_ms_p50\": %.3f, \"pop_ms_p50\": %.3f, \"pcie_GBps_p50\": %.2f, \"frames_released\": %ld, "
            "\"frames_wrong\": %ld, \"frames_imperfect\": %ld, \"rounds_not_one_frame_per_stream\": %ld}\n",
-           N, rounds, pct(t_round, 0.5), pct(t_round, 0.99), pct(t_round, 1.0), pct(t_push, 0.5), pct(t_proc, 0.5), pct(t_pop, 0.5),
+           N, pipelined ? "true" : "false", rounds, pct(t_round, 0.5), pct(t_round, 0.99), pct(t_round, 1.0), pct(t_push, 0.5), pct(t_proc, 0.5), pct(t_pop, 0.5),
            (double)N * chunk * 4 / (pct(t_push, 0.5) * 1e-3) / 1e9, released, wrong, imperfect, uneven);
     opv_destroy(ctx);
     (void)hipHostFree(iq);

@@ -28,7 +28,7 @@ CHUNK_SAMPLES = 86720
 SAMPLE_RATE = 2168000.0
 
 EXPORTS = [
-    "opv_create", "opv_destroy", "opv_last_error", "opv_abi_version", "opv_push_iq", "opv_push_iq_batch", "opv_flush",
+    "opv_create", "opv_destroy", "opv_last_error", "opv_abi_version", "opv_push_iq", "opv_push_iq_batch", "opv_push_iq_batch_async", "opv_push_wait", "opv_flush",
     "opv_attach_device_iq", "opv_process", "opv_sync", "opv_set_frontend", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_comm_unique_id", "opv_comm_init", "opv_comm_init_all",
     "opv_comm_destroy", "opv_gather_frames", "opv_gather_frames_all", "opv_tap_soft", "opv_tap_chunks",
@@ -99,6 +99,8 @@ def lib():
         L.opv_push_iq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.opv_flush.argtypes = [C.c_void_p, C.c_int]
         L.opv_push_iq_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.opv_push_iq_batch_async.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.opv_push_wait.argtypes = [C.c_void_p]
         L.opv_attach_device_iq.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
         L.opv_process.argtypes = [C.c_void_p]
         L.opv_sync.argtypes = [C.c_void_p]
@@ -314,14 +316,23 @@ class Demod:
         iq = np.ascontiguousarray(iq, np.int16).reshape(-1)
         _chk(lib().opv_push_iq(self.h, stream, iq.ctypes.data, iq.size // 2))
 
-    def push_batch(self, streams, blocks):
-        """opv_push_iq_batch: blocks[i] (int16 IQ) goes to streams[i]; one wait for all copies."""
+    def push_batch(self, streams, blocks, wait=True):
+        """opv_push_iq_batch: blocks[i] (int16 IQ) goes to streams[i]; one wait for all copies. wait=False:
+        opv_push_iq_batch_async - the blocks must stay alive and unchanged until push_wait() (they are kept referenced here)."""
         blocks = [np.ascontiguousarray(b, np.int16).reshape(-1) for b in blocks]
         n = len(blocks)
         ids = (C.c_int * n)(*[int(s) for s in streams])
         ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in blocks])
         lens = (C.c_size_t * n)(*[b.size // 2 for b in blocks])
-        _chk(lib().opv_push_iq_batch(self.h, n, ids, ptrs, lens))
+        if wait:
+            _chk(lib().opv_push_iq_batch(self.h, n, ids, ptrs, lens))
+        else:
+            self._inflight = blocks
+            _chk(lib().opv_push_iq_batch_async(self.h, n, ids, ptrs, lens))
+
+    def push_wait(self):
+        _chk(lib().opv_push_wait(self.h))
+        self._inflight = None
 
     def flush(self, stream):
         _chk(lib().opv_flush(self.h, stream))

@@ -141,6 +141,10 @@ int opv_push_iq_batch(opv_ctx* c, int count, const int* streams, const int16_t* 
         if (int r = opv_push_iq(c, streams[i], iq[i], n[i])) return r;
     return OPV_OK;
 }
+int opv_push_iq_batch_async(opv_ctx* c, int count, const int* streams, const int16_t* const* iq, const size_t* n) {
+    return opv_push_iq_batch(c, count, streams, iq, n);   // (the stand-in has copied everything when it returns)
+}
+int opv_push_wait(opv_ctx* c) { return c ? OPV_OK : OPV_EINVAL; }
 int opv_flush(opv_ctx* c, int stream) {
     FakeStream* f = stream_of(c, stream);
     if (!f) return OPV_EINVAL;

@@ -1702,18 +1702,19 @@ def test_push_batch_and_pooled_pops(amd, oracle, iq10):
     d.close()
 
 
-@pytest.mark.parametrize("gather", [True, False])
-def test_push_batch_from_pinned_memory_and_batched_compaction(amd, oracle, iq10, iq100, gather, monkeypatch):
+@pytest.mark.parametrize("mode", ["gather", "copies", "async"])
+def test_push_batch_from_pinned_memory_and_batched_compaction(amd, oracle, iq10, iq100, mode, monkeypatch):
     """The serving path's bulk moves (csrc/opv_capi.hip: k_push_gather, k_compact). Blocks that lie in PINNED host memory cross
     PCIe through one gather kernel per opv_push_iq_batch (read through their device-visible addresses) instead of one copy per
     stream, and staging buffers that fill in the same round are compacted by one launch. 14 streams with a staging buffer of
     about three chunks (so every stream compacts every few rounds, most of them together), blocks of ragged sizes: 16-byte
     aligned ones, ones starting one, two or three samples into a quad (4-byte moves), lengths that are no multiple of four
     samples, a stream with two blocks in one batch, a block from PAGEABLE memory in the same batch (takes hipMemcpyAsync), and
-    a stream whose second block of a batch forces its own compaction. gather=False (OPV_PUSH_NO_GATHER) runs the same rounds
-    over the per-stream copies. Every stream's frames, metrics, sync positions, tracker lines and soft symbols equal the oracle's."""
+    a stream whose second block of a batch forces its own compaction. mode "copies" (OPV_PUSH_NO_GATHER) runs the same rounds
+    over the per-stream copies; mode "async" enqueues every batch with opv_push_iq_batch_async and calls opv_process BEFORE
+    opv_push_wait (the kernels must queue behind the moves on the device). Every stream's frames, metrics, sync positions, tracker lines and soft symbols equal the oracle's."""
     import torch
-    if not gather:
+    if mode == "copies":
         monkeypatch.setenv("OPV_PUSH_NO_GATHER", "1")
     caps = [impair(iq100[: 2 * 86720 * 30], amp=2500.0, f0_hz=-1500.0 + 230.0 * k, ebn0_db=15.0, seed=70 + k) for k in range(12)]
     caps += [iq100[: 2 * 86720 * 30].copy(), iq10.copy()]
@@ -1739,8 +1740,13 @@ def test_push_batch_from_pinned_memory_and_batched_compaction(amd, oracle, iq10,
                 if n > 0:
                     src = pinned[k][1] if not (k == 7 and r % 3 == 1) else caps[k]       # stream 7: every third round from pageable memory
                     ids.append(k); blks.append(src[2 * at[k]: 2 * (at[k] + n)]); at[k] += n
-        d.push_batch(ids, blks)
-        d.process()
+        if mode == "async":
+            d.push_batch(ids, blks, wait=False)
+            d.process()
+            d.push_wait()
+        else:
+            d.push_batch(ids, blks)
+            d.process()
         for k in range(S):
             fr, meta = d.pop_frames(k)
             frames[k].append((fr, meta))
