@@ -644,9 +644,14 @@ static int push_deferred(opv_ctx* c, const std::vector<DeferredCopy>& copies) {
     if (m) {
         void* d_pairs = nullptr;
         HIPCHK(hipHostGetDevicePointer(&d_pairs, pairs, 0));
-        const uint32_t slices = m >= 1024 ? 1 : (1024 + m - 1) / m;   // >= 1024 work items: enough 16-byte loads in flight for the link
+        // A SMALL grid on purpose: PCIe's latency x bandwidth product is ~120 KB, and 32 blocks x 256 lanes x 16 B = 128 KB of
+        // reads in flight already run the link at its rate (56 GB/s; 16 blocks: 45). More does not move more - but it fills the
+        // memory system's request queues with reads that take microseconds, and the kernels of an opv_process running beside an
+        // asynchronous batch then crawl (5120 streams: round kernels 3.5 ms beside 32 blocks, 18 ms beside 128, 27 ms beside 256).
+        const uint32_t slices = m >= 1024 ? 1 : (1024 + m - 1) / m;   // work items of <= 347 KB / slices: an even load over the blocks
         uint32_t grid = m * slices;
-        if (grid > 1024) grid = 1024;
+        static const uint32_t max_grid = [] { const char* e = std::getenv("OPV_PUSH_GATHER_BLOCKS"); const int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 32); }();   // (dev switch)
+        if (grid > max_grid) grid = max_grid;
         k_push_gather<<<grid, 256, 0, c->copy_stream>>>((const PushPair*)d_pairs, m, slices);
         HIPCHK(hipGetLastError());
     }

@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
     std::vector<const int16_t*> ptrs(N);
     std::vector<size_t> lens(N, chunk);
     for (int k = 0; k < N; ++k) ids[k] = k;
-    std::vector<double> t_round, t_push, t_proc, t_pop;
+    std::vector<double> t_round, t_push, t_proc, t_pop, t_launch, t_enq;
     uint8_t out[4 * OPV_FRAME_BYTES];
     opv_frame_meta meta[4];
     long released = 0, wrong = 0, imperfect = 0, uneven = 0;
@@ -92,10 +92,12 @@ int main(int argc, char** argv) {
         }
         const auto t1 = clk::now();
         if (opv_process(ctx) < 0) { fprintf(stderr, "process: %s\n", opv_last_error()); return 2; }
+        const auto t1a = clk::now();
         if (pipelined && r + 1 < total) {                 // round r + 1 starts crossing PCIe behind round r's launches
             set_ptrs(r + 1);
             if (opv_push_iq_batch_async(ctx, N, ids.data(), ptrs.data(), lens.data()) < 0) { fprintf(stderr, "push: %s\n", opv_last_error()); return 2; }
         }
+        const auto t1b = clk::now();
         if (opv_sync(ctx) < 0) { fprintf(stderr, "process: %s\n", opv_last_error()); return 2; }
         const auto t2 = clk::now();
         long got_round = 0;
@@ -117,6 +119,8 @@ int main(int argc, char** argv) {
             t_push.push_back(ms(t0, t1));
             t_proc.push_back(ms(t1, t2));
             t_pop.push_back(ms(t2, t3));
+            t_launch.push_back(ms(t1, t1a));
+            t_enq.push_back(ms(t1a, t1b));
         }
     }
     auto pct = [](std::vector<double> v, double p) {
@@ -126,9 +130,9 @@ int main(int argc, char** argv) {
     };
     printf("{\"streams\": %d, \"pipelined\": %s, \"rounds\": %d, \"signal_ms_per_round\": 40.0, \"round_ms_p50\": %.3f, \"round_ms_p99\": %.3f, \"round_ms_max\": %.3f, "
            "\"push_ms_p50\": %.3f, \"process_ms_p50\": %.3f, \"pop_ms_p50\": %.3f, \"pcie_GBps_p50\": %.2f, \"frames_released\": %ld, "
-           "\"frames_wrong\": %ld, \"frames_imperfect\": %ld, \"rounds_not_one_frame_per_stream\": %ld}\n",
+           "\"frames_wrong\": %ld, \"frames_imperfect\": %ld, \"rounds_not_one_frame_per_stream\": %ld, \"process_call_ms_p50\": %.3f, \"async_enqueue_ms_p50\": %.3f}\n",
            N, pipelined ? "true" : "false", rounds, pct(t_round, 0.5), pct(t_round, 0.99), pct(t_round, 1.0), pct(t_push, 0.5), pct(t_proc, 0.5), pct(t_pop, 0.5),
-           (double)N * chunk * 4 / (pct(t_push, 0.5) * 1e-3) / 1e9, released, wrong, imperfect, uneven);
+           (double)N * chunk * 4 / (pct(t_push, 0.5) * 1e-3) / 1e9, released, wrong, imperfect, uneven, pct(t_launch, 0.5), pct(t_enq, 0.5));
     opv_destroy(ctx);
     (void)hipHostFree(iq);
     return wrong ? 1 : 0;
