@@ -142,20 +142,23 @@ def _n_gpus():
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 GPUs: RCCL refuses two ranks on one device (armed for an N-GPU box)")
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [1, 2, 4])
 def test_bench_worldN_over_rccl_under_the_drivers_launcher(world):
-    """ARMED FOR AN N-GPU BOX (skipped on the 1-GPU pool): the driver's own N > 1 command with NO rehearsal switch - rank r on
-    cuda:r, init_process_group("nccl") = RCCL over xGMI, the frame gather and the MAX of the step time on device tensors. Same
-    checks as the gloo rehearsal: rank shards, callsigns read back from the gathered bytes, whole-job value."""
+    """ARMED FOR AN N-GPU BOX (worlds 2 and 4 are skipped on the 1-GPU pool; world 1 runs there, so that only the other ranks
+    are new on a bigger box): the driver's own launcher command with NO rehearsal switch - rank r on cuda:r,
+    init_process_group("nccl") = RCCL over xGMI, the frame gather and the MAX of the step time on device tensors. Same checks as
+    the gloo rehearsal: rank shards, callsigns read back from the gathered bytes, whole-job value."""
     import socket
     if _n_gpus() < world:
-        pytest.skip(f"{_n_gpus()} GPUs visible, {world} needed")
+        pytest.skip(f"needs >= {world} GPUs, {_n_gpus()} visible: RCCL refuses two ranks on one device (armed for an N-GPU box)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = {k: v for k, v in _world2_env().items() if k not in ("OPV_BENCH_BACKEND", "OPV_BENCH_SHARE_DEVICE")}
     args = ["--gpus", str(world)] + WORLD2_ARGS[2:]
+    if world == 1:
+        env["OPV_BENCH_FORCE_DIST"] = "1"                  # (one rank takes bench.py's N > 1 path only when told to)
+        args.append("--no-big")                            # (and a one-rank line carries extras: not the minutes-long ones)
     launch = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
               "--master-port", str(port), str(ROOT / "bench.py")] + args
     p = subprocess.run([sys.executable] + launch, env=env, capture_output=True, text=True, timeout=420)

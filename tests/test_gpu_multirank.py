@@ -157,11 +157,20 @@ def test_c_side_gather_frames_all_over_two_devices():
     opv_gather_frames_all, the N ranks' ncclGathers issued by one thread inside one RCCL group): a context per device, each on
     its own shard of 6 streams, frames and counts gathered into device 0's HBM; the gathered [N][S][cap][134] / [N][S] equal
     every context's own buffers and every global stream's frames the oracle's."""
+    _gather_all_in_one_process(min(_n_gpus(), 4))
+
+
+def test_c_side_gather_frames_all_world_1():
+    """the body of the armed test above on the one device of the pool (opv_comm_init_all / opv_gather_frames_all with n = 1), so
+    that on an N-GPU box only the second device is new to it"""
+    _gather_all_in_one_process(1)
+
+
+def _gather_all_in_one_process(N):
     import torch
     from __graft_entry__ import load_opv_amd, load_pkg_module
     from oracle_lib import Oracle
     amd, workload = load_opv_amd(), load_pkg_module("workload")
-    N = min(_n_gpus(), 4)
     S, F = 6, 5
     n = amd.lib().opv_tx_modulated_samples(F)
     dms, iqs, views = [], [], []
