@@ -870,19 +870,6 @@ extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_rb_wg4(OpvStrea
     __syncthreads();
     msk_frontend_body<4, 0, 1>(streams, cfg, n_streams, lds_all);
 }
-#ifdef OPV_WITH_WG6
-// EXPERIMENT (round 5, `make wg6`; not in the product): SIX one-wave streams per workgroup = two waves on two of a CU's four SIMDs,
-// which forces the body into 256 VGPRs - the "two waves per SIMD" regime of the 1025 - 2048 stream range with the present 8 KB
-// tiles (6 x 16 400 + 32 800 B of LDS; eight waves would miss the 160 KB by 160 B). Selected by OPV_WG6=1 in a library built
-// with -DOPV_WITH_WG6. DESIGN.md §7 has the measurement.
-extern "C" __global__ __launch_bounds__(384) void k_msk_frontend_rb_wg6(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
-                                                                         int n_streams) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[6 * kTabOff + kAtanQBytes];
-    load_atan_table_q<384>(lds_all + 6 * kTabOff);
-    __syncthreads();
-    msk_frontend_body<6, 0, 1>(streams, cfg, n_streams, lds_all);
-}
-#endif
 #ifdef OPV_WITH_COMPARISON_MAPPINGS
 // two waves per stream: wave 0 = timing loop (ROLE 1), wave 1 = AFC (ROLE 2), on two SIMDs of one CU
 extern "C" __global__ __launch_bounds__(128) void k_msk_frontend_dual(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,

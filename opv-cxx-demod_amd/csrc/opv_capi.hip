@@ -30,9 +30,6 @@ extern "C" __global__ void k_msk_frontend_dual(OpvStream*, OpvGlobalCfg, int);
 #endif
 extern "C" __global__ void k_msk_frontend_rb(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_rb_wg4(OpvStream*, OpvGlobalCfg, int);
-#ifdef OPV_WITH_WG6   // `make wg6`: the two-waves-per-SIMD experiment (k_frontend.hip), selected by OPV_WG6=1
-extern "C" __global__ void k_msk_frontend_rb_wg6(OpvStream*, OpvGlobalCfg, int);
-#endif
 extern "C" __global__ void k_msk_frontend_x4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x16(OpvStream*, OpvGlobalCfg, int);
@@ -874,12 +871,6 @@ extern "C" int opv_process(opv_ctx* c) {
     }
     // one wave per stream, row-broadcast reduction (k_frontend.hip: symbol_r). Its 272-278 registers allow one wave per SIMD;
     // four waves per workgroup (one per SIMD of a CU by construction) as soon as single-wave workgroups could double up
-#ifdef OPV_WITH_WG6
-    else if (S > kFrontendWg4MinStreams && std::getenv("OPV_WG6")) {
-        c->last_frontend = "k_msk_frontend_rb_wg6";
-        k_msk_frontend_rb_wg6<<<(S + 5) / 6, 384, 0, c->stream>>>(c->d_streams, g, S);
-    }
-#endif
     else if (S > kFrontendWg4MinStreams) {
         c->last_frontend = "k_msk_frontend_rb_wg4";
         k_msk_frontend_rb_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S);

@@ -1,6 +1,7 @@
 """EXPERIMENT (round 5): the one-wave front-end with SIX streams per workgroup (two waves on a SIMD, 256 VGPRs:
 `make -C opv-cxx-demod_amd wg6`, OPV_LIB=.../build/wg6/libopv_demod_hip.so) beside the shipped four-per-workgroup launch, at 1024 ... 2048
 streams: front-end time, cycles per symbol of the waves, and whether every stream's frames are the same.
+(needs the tree of commit 55ab88e, which carries the kernel and `make wg6`)
 usage (GPU box): OPV_LIB=$PWD/opv-cxx-demod_amd/build/wg6/libopv_demod_hip.so python scripts/experiments/wg6_probe.py"""
 import os
 import sys
