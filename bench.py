@@ -137,14 +137,22 @@ def live_capacity(dev_index):
     if not exe.exists():
         return None
     probes = {}
+    t_end = time.perf_counter() + 150.0                # the whole search is bounded: the bench line must not wait minutes for an extra
 
     def probe(n, pipelined=False):
         key = (n, pipelined)
         if key not in probes:
-            p = subprocess.run([str(exe), str(n), "120", "6", str(dev_index)] + (["--pipelined"] if pipelined else []),
-                               capture_output=True, text=True, timeout=240)
-            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-            probes[key] = json.loads(line[-1]) if p.returncode == 0 and line else {"streams": n, "pipelined": pipelined, "error": (p.stderr or p.stdout)[-200:], "rc": p.returncode}
+            left = t_end - time.perf_counter()
+            if left < 10.0:
+                probes[key] = {"streams": n, "pipelined": pipelined, "error": "search time used up (150 s)", "rc": None}
+                return False
+            try:
+                p = subprocess.run([str(exe), str(n), "120", "6", str(dev_index)] + (["--pipelined"] if pipelined else []),
+                                   capture_output=True, text=True, timeout=min(60.0, left))
+                line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+                probes[key] = json.loads(line[-1]) if p.returncode == 0 and line else {"streams": n, "pipelined": pipelined, "error": (p.stderr or p.stdout)[-200:], "rc": p.returncode}
+            except subprocess.TimeoutExpired:
+                probes[key] = {"streams": n, "pipelined": pipelined, "error": "probe timed out", "rc": None}
         r = probes[key]
         return "error" not in r and r["round_ms_p99"] < 40.0 and r["frames_wrong"] == 0
     lo, hi = 0, None
