@@ -550,7 +550,7 @@ static int compact_streams(opv_ctx* c, const std::vector<int>& which) {
     CompactItem* items = nullptr;
     PushPair* pairs = nullptr;
     if (int r = bulk_table(c, (size_t)c->n_streams, &items, &pairs)) return r;
-    uint32_t m = 0;
+    uint32_t m = 0, most = 0;
     for (int s : which) {
         HostStream& h = c->hs[s];
         OpvStream& st = c->mirror[s];
@@ -559,6 +559,7 @@ static int compact_streams(opv_ctx* c, const std::vector<int>& which) {
         const uint64_t len = h.n_avail - keep;
         if (!h.d_iq_alt) HIPCHK(hipMalloc(&h.d_iq_alt, h.iq_cap * 4 + 16384));
         items[m++] = {(const int*)(h.d_iq_owned + 2 * keep), (int*)h.d_iq_alt, (uint32_t)len, (uint32_t)s, keep};
+        if ((uint32_t)len > most) most = (uint32_t)len;
         std::swap(h.d_iq_owned, h.d_iq_alt);
         h.d_iq = h.d_iq_owned;
         h.n_avail -= keep;
@@ -572,7 +573,9 @@ static int compact_streams(opv_ctx* c, const std::vector<int>& which) {
     if (m) {
         void* d_items = nullptr;
         HIPCHK(hipHostGetDevicePointer(&d_items, items, 0));
-        const uint32_t slices = m >= 1024 ? 1 : (1024 + m - 1) / m;
+        uint32_t slices = m >= 1024 ? 1 : (1024 + m - 1) / m;
+        const uint32_t by_size = most / (256u * 4u);                  // (samples: one 16-byte move per lane of a block at least)
+        if (slices > by_size) slices = by_size ? by_size : 1;
         uint32_t grid = m * slices;
         if (grid > 2048) grid = 2048;
         k_compact<<<grid, 256, 0, c->stream>>>(c->d_streams, (const CompactItem*)d_items, m, slices);   // in stream order before the next kernels
@@ -623,7 +626,7 @@ static int push_deferred(opv_ctx* c, const std::vector<DeferredCopy>& copies) {
     if (copies.empty()) return OPV_OK;
     CompactItem* items = nullptr;
     PushPair* pairs = nullptr;
-    uint32_t m = 0;
+    uint32_t m = 0, most = 0;
     const bool try_gather = copies.size() >= 2 && !std::getenv("OPV_PUSH_NO_GATHER");   // (test hook: the per-stream copies)
     if (try_gather)
         if (int r = bulk_table(c, copies.size() > (size_t)c->n_streams ? copies.size() : (size_t)c->n_streams, &items, &pairs)) return r;
@@ -634,6 +637,7 @@ static int push_deferred(opv_ctx* c, const std::vector<DeferredCopy>& copies) {
             if (hipPointerGetAttributes(&at, k.src) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
                 const uint32_t wide = (((uintptr_t)at.devicePointer | (uintptr_t)k.dst) & 15u) == 0 ? 1u : 0u;
                 pairs[m++] = {at.devicePointer, k.dst, (uint32_t)k.bytes, wide};
+                if ((uint32_t)k.bytes > most) most = (uint32_t)k.bytes;
                 gathered = true;
             } else {
                 (void)hipGetLastError();                   // (pageable memory: "invalid value" - not an error of ours)
@@ -648,7 +652,9 @@ static int push_deferred(opv_ctx* c, const std::vector<DeferredCopy>& copies) {
         // reads in flight already run the link at its rate (56 GB/s; 16 blocks: 45). More does not move more - but it fills the
         // memory system's request queues with reads that take microseconds, and the kernels of an opv_process running beside an
         // asynchronous batch then crawl (5120 streams: round kernels 3.5 ms beside 32 blocks, 18 ms beside 128, 27 ms beside 256).
-        const uint32_t slices = m >= 1024 ? 1 : (1024 + m - 1) / m;   // work items of <= 347 KB / slices: an even load over the blocks
+        uint32_t slices = m >= 1024 ? 1 : (1024 + m - 1) / m;         // work items of <= 347 KB / slices: an even load over the blocks ...
+        const uint32_t by_size = most / (256u * 16u);                 // ... but never thinner than one 16-byte move per lane of a block
+        if (slices > by_size) slices = by_size ? by_size : 1;
         uint32_t grid = m * slices;
         static const uint32_t max_grid = [] { const char* e = std::getenv("OPV_PUSH_GATHER_BLOCKS"); const int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 32); }();   // (dev switch)
         if (grid > max_grid) grid = max_grid;
