@@ -119,8 +119,9 @@ typedef struct opv_stream_state {
     int32_t stalled;          /* back-pressure after the last opv_process: bit 0 = soft-symbol ring full, bit 1 = ring of
                                  unpopped frames full. The stream resumes at the next opv_process after opv_pop_frames */
     int32_t offset_ties;      /* offset-search candidates that were within 1e-11 (relative energy) of the winner and were
-                                 therefore re-evaluated in the reference's own order of operations (estimate_offset :143-159) -
-                                 on the host, with the host's sin / cos (the reference's libm), when opv_offset_ties_on_host() is 1 */
+                                 therefore re-evaluated in the reference's own order of operations (estimate_offset :143-159): on
+                                 the device, and once more on the host with the host's sin / cos (the reference's libm) if two of
+                                 them are then still within 2e-13 of each other and opv_offset_ties_on_host() is 1 */
 } opv_stream_state;
 
 typedef struct opv_ctx opv_ctx;
@@ -246,8 +247,9 @@ long opv_tap_soft(opv_ctx* ctx, int stream, uint64_t first_symbol, double* out, 
 long opv_tap_chunks(opv_ctx* ctx, int stream, uint32_t first_chunk, double* out5, size_t cap_chunks);
 /* 134 candidate energies of the offset search in scan order (121 coarse, 13 fine) */
 int opv_tap_offset_energies(opv_ctx* ctx, int stream, double* out134);
-/* Who decides the offset search's near-ties (estimate_offset's strict '>' between candidates whose energies differ in the last
- * places of sin / cos, src/opv-demod.cpp:161,195): 1 = the host, with the contenders evaluated by the reference's own loop on the
+/* Who decides the offset search's last-place ties (estimate_offset's strict '>' between candidates whose energies, evaluated in
+ * the reference's order of operations, are within 2e-13 of each other - what the last places of sin / cos can move - or equal,
+ * src/opv-demod.cpp:161,195): 1 = the host, with the contenders evaluated by the reference's own loop on the
  * host's libm - opv_create found that this process's sin / cos reproduce a pinned reference energy (csrc/opv_offset_host.cpp);
  * 0 = the device's sincos (another libm on the host, or OPV_OFFSET_DISTRUST_LIBM set): still the reference's order of
  * operations, counted in offset_ties, but an exact tie is then decided by a different libm than the reference's. */

@@ -28,11 +28,14 @@
 // the reference's order, windows summed in order; only libm's sin / cos are the device's), which shrinks
 // the undecidable band from 1e-13 to the last-place differences of sin / cos. The count of such
 // re-evaluations is reported (opv_stream_state.offset_ties).
-// That last band is closed on the HOST: a stream whose search re-evaluated anything puts its index on `tie_list` and
-// leaves its 19 polynomial coefficients in OpvStream.est_poly; opv_process (opv_capi.hip) then repeats the decision
-// for that stream with the contenders evaluated by opv_offset_candidate_energy (opv_offset_host.cpp) - the reference's
-// loop on the reference's own libm - before the front-end is launched. The device's own decision stands only when the
-// host's libm does not reproduce the pinned energy (tie_list == nullptr then).
+// That last band is closed on the HOST: a stream on which two RE-EVALUATED energies are still within kHostRel = 2e-13 of each
+// other (exact ties included: a real-valued capture) puts its index on `tie_list` and leaves its 19 polynomial coefficients in
+// OpvStream.est_poly; opv_process (opv_capi.hip) then repeats the decision for that stream with the contenders evaluated by
+// opv_offset_candidate_energy (opv_offset_host.cpp) - the reference's loop on the reference's own libm - before the
+// front-end is launched. Re-evaluated contenders further apart than that are decided here: sin / cos cannot move them past
+// each other (bound at kHostRel). Why not every guarded stream: a candidate costs the host 160 000 sin / cos, and a context
+// of 32 768 streams has a dozen guarded ones. The device's own decision stands throughout when the host's libm does not
+// reproduce the pinned energy (tie_list == nullptr then).
 //
 // Roofline: 160 000 B read per stream, once. Compute: see above; no MFMA (the contraction is 40 x 40 per
 // window with weights that differ per tap - a GEMM only in name, and fp64).
@@ -48,6 +51,11 @@ constexpr double kFs = 2168000.0;                        // ref :40
 constexpr double kFdev = 13550.0;                        // ref :42
 constexpr int kK = OPV_OFFS_TERMS;                       // Taylor terms (moments) per tone
 constexpr double kTieRel = 1e-11;                        // "not clearly below the best": 100x the agreement with the reference
+// Second level: after the contenders have been re-evaluated in the reference's order of operations, their energies differ from
+// the reference's only through the last places of sin / cos - a relative 1e-14 at worst (each LO sample within ~2 ulp, 40
+// products per window, the windows' errors added up without cancellation credit). Contenders that are still within kHostRel of
+// the best re-evaluated energy - 20x that bound - go to the host, whose libm IS the reference's; all others are decided here.
+constexpr double kHostRel = 2e-13;
 
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -134,7 +142,8 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
     __shared__ double s_e[134];
     __shared__ double s_scratch[3000];       // exact_energy: 2 x 1000 window-start phases + 1000 window energies
     __shared__ double s_best_e, s_best, s_fine;
-    __shared__ int s_ties;
+    __shared__ int s_ties, s_host;
+    __shared__ unsigned char s_play[134];
 
     // ---- one pass: moments per window, products accumulated into the 19 polynomial coefficients ----------
     double ed[kK], eo[2 * kK - 1];           // sum |m_k|^2 (-> theta^2k) and sum over k > l of Re(rho m_k conj m_l) (-> theta^(k+l))
@@ -198,7 +207,7 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
         v = wave_sum(v);
         if ((tid & 63) == 0) s_red[tid >> 6][p] = v;
     }
-    if (tid == 0) { s_best_e = 0.0; s_best = 0.0; s_fine = 0.0; s_ties = 0; }
+    if (tid == 0) { s_best_e = 0.0; s_best = 0.0; s_fine = 0.0; s_ties = 0; s_host = 0; }
     __syncthreads();
     if (tid < 2 * kK - 1) st.est_poly[tid] = s_poly[tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
     __syncthreads();
@@ -225,17 +234,29 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
             int contenders = (fine && s_best_e >= bar) ? 1 : 0;   // the coarse winner defends its energy
             for (int c = c0; c < c1; ++c) contenders += in_play(c);
             if (contenders > 1) {                         // workgroup-uniform: every thread sees the same LDS values
+                const bool defend = fine && s_best_e >= bar;
                 for (int c = c0; c < c1; ++c) {
-                    if (!in_play(c)) continue;
+                    const bool play = in_play(c);
+                    if (tid == 0) s_play[c] = play ? 1 : 0;
+                    if (!play) continue;
                     const double e = exact_energy(st.iq, nsym, base_offset + step * (double)(c - c0), s_scratch, s_scratch + 2000);
                     __syncthreads();
                     if (tid == 0) { s_e[c] = e; ++s_ties; }
                     __syncthreads();
                 }
-                if (fine && s_best_e >= bar) {
+                if (defend) {
                     const double e = exact_energy(st.iq, nsym, s_best, s_scratch, s_scratch + 2000);
                     __syncthreads();
                     if (tid == 0) { s_best_e = e; ++s_ties; }
+                }
+                __syncthreads();
+                if (tid == 0) {                           // second level: are two re-evaluated energies within what sin / cos could move?
+                    double m = defend ? s_best_e : 0.0;
+                    for (int c = c0; c < c1; ++c)
+                        if (s_play[c]) m = fmax(m, s_e[c]);
+                    int close = (defend && s_best_e >= m * (1.0 - kHostRel)) ? 1 : 0;
+                    for (int c = c0; c < c1; ++c) close += (s_play[c] && s_e[c] >= m * (1.0 - kHostRel)) ? 1 : 0;
+                    if (close > 1) s_host = 1;
                 }
                 __syncthreads();
             }
@@ -264,6 +285,6 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
         st.est_ties = (uint32_t)s_ties;
         st.est_nsym = (uint32_t)nsym;
         st.first_chunk_done = 1;
-        if (s_ties > 0 && tie_list) tie_list[1 + atomicAdd(&tie_list[0], 1u)] = blockIdx.x;   // (capacity: one entry per stream)
+        if (s_host && tie_list) tie_list[1 + atomicAdd(&tie_list[0], 1u)] = blockIdx.x;   // (capacity: one entry per stream)
     }
 }

@@ -329,9 +329,10 @@ def test_offset_search_near_ties_on_ordinary_captures(amd, oracle, host, monkeyp
     """The inputs the host-side tie decision exists for: ORDINARY noisy openings (random start, level, carrier offset, 3 - 22 dB) on
     which two candidates of estimate_offset (ref src/opv-demod.cpp:131-202) differ by less than 1e-11 relative without being
     equal - one opening in about two thousand; these 19 were found with the oracle - so that the strict '>' (:161,195) hangs on
-    the last places of sin / cos. The guard must fire on every one of them; with the contenders re-evaluated on the host (the
-    reference's loop, the reference's libm) the estimate equals the oracle's on all and the re-evaluated energies are the
-    oracle's bit for bit. host=False (the device's sincos re-evaluates: the fallback) runs the same openings and is only counted.
+    the last places of sin / cos. The guard must fire on every one of them and the estimate must equal the oracle's on all. The
+    contenders are re-evaluated in the reference's order on the device first; only those that remain within 2e-13 of each other
+    (what sin / cos could still move, k_offset_search.hip: kHostRel) go to the host's libm - here the finds are 1e-12 ... 1e-11
+    apart, so the device decides them, and host=False (no host at all: the fallback) must agree.
     37 ordinary openings that are no near ties ride along: estimate equal, guard silent."""
     from soak_inputs import near_tie_class, offset_opening
     if not host:
@@ -352,9 +353,7 @@ def test_offset_search_near_ties_on_ordinary_captures(amd, oracle, host, monkeyp
             fired += st.offset_ties >= 2                             # (a find within 1e-13 of the 1e-11 band's edge may sit outside the device's band)
         else:
             assert st.offset_ties == 0 and st.est_offset_hz == off, ids[i]
-        if host:
-            assert st.est_offset_hz == off, (ids[i], st.est_offset_hz, off)
-            assert int(np.sum(g == e)) >= st.offset_ties - 1, ids[i]
+        assert st.est_offset_hz == off, (ids[i], st.est_offset_hz, off, host)
         differ += st.est_offset_hz != off
     print(f"near-tie openings: guard fired on {fired} of {len(NEAR_TIE_OPENINGS)}; host={host}: {differ} estimates differ from the oracle's")
     assert fired >= len(NEAR_TIE_OPENINGS) - 2, fired
@@ -1776,6 +1775,37 @@ def test_push_batch_from_pinned_memory_and_batched_compaction(amd, oracle, iq10,
         assert st.total_symbols == exp["n_soft"], k
         a, _ = soft_err(np.concatenate(soft[k]), exp["soft"])
         assert a < SOFT_TIGHT, (k, a)
+    d.close()
+
+
+def test_push_batch_of_tiny_pinned_blocks(amd, oracle, iq10):
+    """the gather route's slicing at its small end: two streams fed from pinned memory in batches whose LARGEST block is 1, 3, 17,
+    255, 1000, 4097 ... samples (fewer bytes than one 16-byte move per lane of a block), then the rest; frames and soft symbols
+    equal the oracle's"""
+    import torch
+    caps = [iq10.copy(), impair(iq10, amp=3000.0, f0_hz=400.0, ebn0_db=17.0, seed=5)]
+    pinned = []
+    for x in caps:
+        t = torch.empty(x.size, dtype=torch.int16).pin_memory()
+        t.numpy()[:] = x
+        pinned.append(t)
+    d = amd.Demod(2, max_samples=iq10.size // 2 + 64, streaming=True)
+    at = 0
+    n_all = iq10.size // 2
+    for n in [1, 3, 17, 255, 1000, 4097, 86720, 5, 50000]:
+        d.push_batch([0, 1], [pinned[k].numpy()[2 * at: 2 * (at + n)] for k in range(2)])
+        d.process()
+        at += n
+    d.push_batch([0, 1], [pinned[k].numpy()[2 * at:] for k in range(2)])
+    for k in range(2):
+        d.flush(k)
+    d.process()
+    for k in range(2):
+        exp = oracle.receive(caps[k], streaming=True)
+        fr, meta = d.pop_frames(k)
+        assert np.array_equal(fr, exp["frames"]) and np.array_equal(meta["viterbi_metric"], exp["metrics"]), k
+        a, _ = soft_err(d.soft(k), exp["soft"])
+        assert a < SOFT_TIGHT and d.state(k).total_symbols == exp["n_soft"], (k, a)
     d.close()
 
 
