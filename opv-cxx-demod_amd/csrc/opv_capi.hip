@@ -762,6 +762,8 @@ static int resolve_offset_ties(opv_ctx* c) {
     HIPCHK(hipMemcpyAsync(c->h_tie_list, c->d_tie_list, sizeof(uint32_t) * head, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     size_t n = c->h_tie_list[0];
+    static const bool debug = std::getenv("OPV_TIE_DEBUG") != nullptr;     // (dev switch: how many streams the host decided)
+    if (debug) fprintf(stderr, "opv: offset search: %zu of %zu streams go to the host's libm\n", n, S);
     if (n == 0) return OPV_OK;
     if (n > S) return fail(OPV_EHIP, "offset search: tie list overrun (internal)");
     if (n + 1 > head) HIPCHK(hipMemcpy(c->h_tie_list + head, c->d_tie_list + head, sizeof(uint32_t) * (n + 1 - head), hipMemcpyDeviceToHost));
