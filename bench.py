@@ -607,10 +607,11 @@ def main():
             sweep[f"{ns}x{nfr}"] = ent
             m.close()
         extras["stream_sweep"] = sweep
-        # PCIe-inclusive: the boundary's host-buffer entry point (opv_push_iq) instead of HBM-resident
-        # captures. Pinned host copies of the first FH frames of every stream are pushed in rounds of RH
-        # frames; opv_push_iq copies on its own HIP stream, so round r+1 crosses PCIe while the
-        # kernels of round r run. Same streams attached in HBM are timed beside it.
+        # PCIe-inclusive: the boundary's host-buffer entry points instead of HBM-resident captures. Pinned host copies of the
+        # first FH frames of every stream are pushed in rounds of RH frames: "host_pushed" with one opv_push_iq per stream (a copy
+        # each, on the library's copy stream), "host_pushed_batched" with one opv_push_iq_batch_async per round (ONE gather kernel
+        # for the 64 blocks; opv_process queues behind it on the device) - either way round r + 1 crosses PCIe while the kernels
+        # of round r run. Same streams attached in HBM are timed beside it.
         FH, RH = min(F, 100), 10
         if FH >= 2 * RH:
             sub_n = FH * FRAME_SAMPLES
@@ -618,7 +619,7 @@ def main():
             host_np = [h.numpy() for h in host]
             hp = amd.Demod(S, max_samples=sub_n + 64, streaming=True, device=dev_index)
             res = {}
-            for mode in ("hbm_attached", "host_pushed", "host_pushed"):
+            for mode in ("hbm_attached", "host_pushed", "host_pushed", "host_pushed_batched", "host_pushed_batched"):
                 hp.reset()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -630,9 +631,14 @@ def main():
                     per = RH * FRAME_SAMPLES
                     for r in range(0, sub_n, per):
                         m = min(per, sub_n - r)
-                        for k in range(S):
-                            hp.push(k, host_np[k][2 * r: 2 * (r + m)])
+                        if mode == "host_pushed_batched":
+                            hp.push_batch(range(S), [host_np[k][2 * r: 2 * (r + m)] for k in range(S)], wait=False)
+                        else:
+                            for k in range(S):
+                                hp.push(k, host_np[k][2 * r: 2 * (r + m)])
                         hp.process()
+                    if mode == "host_pushed_batched":
+                        hp.push_wait()
                     for k in range(S):
                         hp.flush(k)
                     hp.process()

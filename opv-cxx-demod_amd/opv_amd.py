@@ -327,8 +327,10 @@ class Demod:
         if wait:
             _chk(lib().opv_push_iq_batch(self.h, n, ids, ptrs, lens))
         else:
-            self._inflight = blocks
+            held = getattr(self, "_inflight", None)        # the previous batch's blocks stay referenced until the call has waited for them
             _chk(lib().opv_push_iq_batch_async(self.h, n, ids, ptrs, lens))
+            self._inflight = blocks
+            del held
 
     def push_wait(self):
         _chk(lib().opv_push_wait(self.h))
