@@ -388,7 +388,14 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
     } while (0)
 
     HIPCHK_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK_C(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    {   // The copy stream also carries a KERNEL (k_push_gather). The runtime has a handful of hardware queues per priority and
+        // deals streams onto them round-robin: in a process with several contexts the kernel stream and the copy stream of one
+        // context can land on the same queue, and the moves of round r + 1 then wait for the kernels of round r (bench.py's
+        // pcie_inclusive: 109 ms instead of 70). A stream of another PRIORITY comes from another set of queues.
+        int least = 0, greatest = 0;
+        HIPCHK_C(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK_C(hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest));
+    }
     const size_t S = (size_t)n_streams;
     HIPCHK_C(hipHostMalloc(&c->h_in, sizeof(StreamIn) * S * opv_ctx::kInSlots, hipHostMallocDefault));
     for (auto& e : c->in_ev) HIPCHK_C(hipEventCreateWithFlags(&e, hipEventDisableTiming));
