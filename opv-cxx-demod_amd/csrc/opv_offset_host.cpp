@@ -68,11 +68,19 @@ double opv_offset_candidate_energy(const int16_t* iq, size_t nsym, double offset
     } else {
         std::vector<std::thread> pool;
         const size_t per = (nsym + nt - 1) / nt;
+        size_t covered = per < nsym ? per : nsym;             // [0, covered) is this thread's own share
         for (unsigned t = 1; t < nt; ++t) {
             const size_t s0 = t * per, s1 = s0 + per < nsym ? s0 + per : nsym;
-            if (s0 < s1) pool.emplace_back(windows, s0, s1);
+            if (s0 >= s1) break;
+            try {
+                pool.emplace_back(windows, s0, s1);
+            } catch (...) {                                   // no more threads to be had: the rest is done here (same numbers)
+                break;
+            }
+            covered = s1;
         }
         windows(0, per < nsym ? per : nsym);
+        if (covered < nsym && pool.size() + 1 < nt) windows((pool.size() + 1) * per, nsym);
         for (auto& th : pool) th.join();
     }
     double total = 0.0;
