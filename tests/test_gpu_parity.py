@@ -1141,6 +1141,45 @@ def test_rx_bridge_gathers_over_two_devices_in_cxx(amd, oracle, tmp_path):
         socks[k].close()
 
 
+def test_rx_bridge_64_streams_from_pinned_buffers(amd, oracle, tmp_path):
+    """the bridge at the width of one GPU's share of BASELINE configs[4]: 64 inputs (four distinct captures, each named sixteen
+    times) -> one context -> 64 UDP ports. Its read buffers are pinned, so every poll round is ONE opv_push_iq_batch through the
+    gather kernel; every stream's datagrams must be the oracle's frames of its capture, in order."""
+    import socket
+    import subprocess
+    S = 64
+    base = 43000 + (os.getpid() % 300) * 70
+    socks = []
+    for k in range(S):
+        so = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        so.setsockopt(socket.SOL_SOCKET, socket.SO_RCVBUF, 1 << 21)
+        so.bind(("127.0.0.1", base + k))
+        so.setblocking(False)
+        socks.append(so)
+    files, exps = [], []
+    for j in range(4):
+        x = oracle.modulate(oracle.bert_frames(5 + j, f"W{j}", 0xBBAADD, 11 * j))
+        if j % 2:
+            x = impair(x, amp=2800.0, f0_hz=350.0 * j - 600.0, ebn0_db=15.0, seed=30 + j)
+        f = tmp_path / f"w{j}.iq"
+        x.tofile(f)
+        files.append(str(f))
+        exps.append(oracle.receive(x, streaming=True)["frames"])
+    exe = str(amd.PKG / "bin" / "opv-rx-bridge")
+    r = subprocess.run([exe, "-q", "-P", str(base)] + [files[k % 4] for k in range(S)], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    for k in range(S):
+        got = []
+        while True:
+            try:
+                got.append(socks[k].recv(2048))
+            except BlockingIOError:
+                break
+        got = np.frombuffer(b"".join(got), np.uint8).reshape(-1, FRAME_BYTES)
+        assert np.array_equal(got, exps[k % 4]), f"stream {k}: {len(got)} datagrams vs {len(exps[k % 4])} frames"
+        socks[k].close()
+
+
 def test_rx_bridge_udp_and_stdin_sources(amd, oracle, tmp_path):
     """SURVEY.md §8f row 3, the source side: one stream from stdin ('-'), one from UDP datagrams (udp:PORT, ended by
     an empty datagram), one from a file - the three in one GPU context; every stream's output datagrams are the
