@@ -169,7 +169,9 @@ int opv_attach_device_iq(opv_ctx* ctx, int stream, const int16_t* d_iq, size_t n
 /* Runs the hot path on everything that is ready, for all streams, in four launches on the
  * context's HIP stream: offset search (estimate_offset :131-202), MSK front-end
  * (demodulate :206-329 incl. the chunker :1026-1076), sync tracker (:615-736) and frame
- * decode (FrameDecoder::decode :854-898). Asynchronous; opv_sync waits. */
+ * decode (FrameDecoder::decode :854-898). Asynchronous; opv_sync waits. (One host wait inside: in the round in which a stream's
+ * offset search runs - its first full chunk, or EOF in batch mode - the call waits for that one kernel, because a search whose
+ * candidates tie in the last places of sin / cos is decided with the host's libm before the front-end starts.) */
 int opv_process(opv_ctx* ctx);
 int opv_sync(opv_ctx* ctx);
 /* Stream-to-wavefront mapping of the front-end kernel (no counterpart in the reference, which is one thread
