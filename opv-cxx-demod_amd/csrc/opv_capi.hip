@@ -641,7 +641,9 @@ static int push_deferred(opv_ctx* c, const std::vector<DeferredCopy>& copies) {
         bool gathered = false;
         if (try_gather && ((uintptr_t)k.src & 3u) == 0 && k.bytes < (1ull << 32)) {
             hipPointerAttribute_t at;
-            if (hipPointerGetAttributes(&at, k.src) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+            // (pinned memory that belongs to ANOTHER device's context is left to hipMemcpyAsync: whether this device may read it in a
+            // kernel depends on how it was allocated, and a wrong guess is a page fault, not an error code)
+            if (hipPointerGetAttributes(&at, k.src) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer && at.device == c->cfg.device) {
                 const uint32_t wide = (((uintptr_t)at.devicePointer | (uintptr_t)k.dst) & 15u) == 0 ? 1u : 0u;
                 pairs[m++] = {at.devicePointer, k.dst, (uint32_t)k.bytes, wide};
                 if ((uint32_t)k.bytes > most) most = (uint32_t)k.bytes;

@@ -145,7 +145,8 @@ int main(int argc, char** argv) {
     // moves blocks that lie in pinned memory with one gather kernel at the link's rate instead of one copy per stream
     constexpr size_t kStride = kRound + kDgram + 16;
     unsigned char* bufs = nullptr;
-    bool bufs_pinned = hipHostMalloc((void**)&bufs, (size_t)S * kStride, hipHostMallocPortable) == hipSuccess;
+    // (one context only: with a context per GPU the buffers would have to be pinned per device; pageable then, as before)
+    bool bufs_pinned = D == 1 && hipSetDevice(devices[0]) == hipSuccess && hipHostMalloc((void**)&bufs, (size_t)S * kStride, hipHostMallocDefault) == hipSuccess;
     if (!bufs_pinned) bufs = (unsigned char*)malloc((size_t)S * kStride);     // (pageable works too: per-stream copies)
     if (!bufs) { fprintf(stderr, "opv-rx-bridge: out of host memory\n"); return 2; }
     std::vector<int> pending_flush;
