@@ -393,8 +393,12 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
         // context can land on the same queue, and the moves of round r + 1 then wait for the kernels of round r (bench.py's
         // pcie_inclusive: 109 ms instead of 70). A stream of another PRIORITY comes from another set of queues.
         int least = 0, greatest = 0;
-        HIPCHK_C(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK_C(hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest));
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+            (void)hipGetLastError();                       // (no priorities here: an ordinary stream - correct, the overlap is then up to the queue deal)
+            c->copy_stream = nullptr;
+            HIPCHK_C(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        }
     }
     const size_t S = (size_t)n_streams;
     HIPCHK_C(hipHostMalloc(&c->h_in, sizeof(StreamIn) * S * opv_ctx::kInSlots, hipHostMallocDefault));
