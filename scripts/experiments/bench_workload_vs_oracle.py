@@ -1,5 +1,6 @@
 """one-off soak: EVERY stream of bench.py's workload (64 streams x 1000 frames, 16 dB, f0 -2000..+2000 Hz: BASELINE configs[3])
-through the HIP path in one context, and through the CPU oracle (8 worker processes, one stream at a time in host memory):
+through the HIP path in one context, and through the CPU oracle (a worker process per host core, one stream each at a time in host memory;
+`512 1000` is BASELINE configs[4]'s whole workload, global streams 0..511, on one GPU):
 frames, Viterbi metrics, sync positions, tracker events (kind / count / symbol), symbol count, offset estimate of every stream.
 tests/test_gpu_parity.py::test_config3_full_size_all_streams does the same in every suite run (round 4); this prints a line per stream."""
 import sys
@@ -14,7 +15,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
-from soak_inputs import oracle_receive_job as oracle_job  # noqa: E402  (shared with tests/test_gpu_parity.py)
+from soak_inputs import host_workers, oracle_receive_job as oracle_job  # noqa: E402  (shared with tests/test_gpu_parity.py)
 
 
 def main():
@@ -34,11 +35,12 @@ def main():
     dm.sync()
     print(f"HIP path: {S} streams x {F} frames in {time.time() - t0:.2f} s ({dm.frontend_kernel()})", flush=True)
     bad = 0
-    with ProcessPoolExecutor(8) as pool:
+    W = host_workers()
+    with ProcessPoolExecutor(W) as pool:
         pending = {}
         for k in range(S):
             pending[k] = pool.submit(oracle_job, d_iq[k].cpu().numpy())
-            if len(pending) >= 8 or k == S - 1:
+            if len(pending) >= W or k == S - 1:
                 for j, fut in sorted(pending.items()):
                     e = fut.result()
                     fr, meta = dm.pop_frames(j)
