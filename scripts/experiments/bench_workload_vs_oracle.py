@@ -24,16 +24,17 @@ def main():
     amd, workload = load_opv_amd(), load_pkg_module("workload")
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     F = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    ebn0 = float(sys.argv[3]) if len(sys.argv) > 3 else 16.0        # (12 / 6 dB: the noise-dominated parity of SURVEY.md §7-5 on all streams)
     dev = torch.device("cuda", 0)
     n = amd.lib().opv_tx_modulated_samples(F)
     dm = amd.Demod(S, max_samples=n + 64, streaming=True)
-    d_iq, tx, n = workload.generate(amd, dm, torch, dev, range(S), F, 16.0)
+    d_iq, tx, n = workload.generate(amd, dm, torch, dev, range(S), F, ebn0)
     for k in range(S):
         dm.attach(k, d_iq[k].data_ptr(), n, eof=True)
     t0 = time.time()
     dm.process()
     dm.sync()
-    print(f"HIP path: {S} streams x {F} frames in {time.time() - t0:.2f} s ({dm.frontend_kernel()})", flush=True)
+    print(f"HIP path: {S} streams x {F} frames at Eb/N0 {ebn0:g} dB in {time.time() - t0:.2f} s ({dm.frontend_kernel()})", flush=True)
     bad = 0
     W = host_workers()
     with ProcessPoolExecutor(W) as pool:
@@ -52,7 +53,7 @@ def main():
                           and st.total_symbols == e["n_soft"] and st.est_offset_hz == e["est_offset"]
                           and abs(st.freq_offset_hz - e["final_freq_offset"]) < 1e-6 and st.edge_ties == 0)
                     bad += not ok
-                    print(f"stream {j:3d}: {len(fr)} frames, {int((fr == tx[j][:len(fr)]).all(axis=1).sum())} equal to the transmitted ones, "
+                    print(f"stream {j:3d}: {len(fr)} frames, {int((fr[:F] == tx[j][:len(fr)]).all(axis=1).sum()) if len(fr) <= F else -1} equal to the transmitted ones, "
                           f"{len(ev)} tracker events, est {st.est_offset_hz:+.0f} Hz, final AFC {st.freq_offset_hz:+.3f} Hz (oracle {e['final_freq_offset']:+.3f}), "
                           f"offset_ties {st.offset_ties}: {'== oracle' if ok else 'DIFFERS'}", flush=True)
                 pending = {}
