@@ -1188,6 +1188,24 @@ def test_rx_bridge_64_streams_from_pinned_buffers(amd, oracle, tmp_path):
         socks[k].close()
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_live_capacity_tool_checks_what_it_times(amd, pipelined):
+    """bin/opv-live-capacity (bench.py extras.live_capacity; a C++ caller of the C ABI like the bridge): 200 streams, 12 serving
+    rounds - every stream listens to one long BERT run from its own frame on, each round pushes one 40 ms chunk per stream from
+    pinned host memory, processes, pops. The tool compares every popped frame with what was sent: none wrong, all perfect, one frame
+    per stream and round - in the serial loop and in the double-buffered one (opv_push_iq_batch_async / opv_push_wait)."""
+    import json
+    import subprocess
+    exe = str(amd.PKG / "bin" / "opv-live-capacity")
+    r = subprocess.run([exe, "200", "12", "3", "0"] + (["--pipelined"] if pipelined else []), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["streams"] == 200 and j["pipelined"] is pipelined and j["rounds"] == 12
+    assert j["frames_wrong"] == 0 and j["frames_imperfect"] == 0 and j["rounds_not_one_frame_per_stream"] == 0
+    assert j["frames_released"] == 200 * 14                      # 15 rounds in all, the first one releases nothing
+    assert 0.0 < j["round_ms_p50"] < 40.0
+
+
 def test_rx_bridge_udp_and_stdin_sources(amd, oracle, tmp_path):
     """SURVEY.md §8f row 3, the source side: one stream from stdin ('-'), one from UDP datagrams (udp:PORT, ended by
     an empty datagram), one from a file - the three in one GPU context; every stream's output datagrams are the
