@@ -235,3 +235,42 @@ def test_oracle_tx_and_decoder_edges_under_asan(san):
     assert p.returncode in (0, 1) and b"PLL bandwidth: 35.0 Hz" in p.stderr
     p = run([b["opv-demod"], "-r", "-q"], bytes(4 * 300000))
     assert p.returncode == 1 and p.stdout == b""
+
+
+@pytest.mark.parametrize("variant", ["asan", "tsan"])
+def test_offset_tie_host_evaluation_under_sanitizers(variant, tmp_path):
+    """csrc/opv_offset_host.cpp - the one piece of host ARITHMETIC in the product library (offset-search candidates whose order the
+    last places of sin / cos decide, evaluated by the reference's loop on up to eight threads) - under ASan + UBSan and under TSan:
+    a candidate's energy, the whole two-stage decision on an exactly tying (real-valued) capture and the libm probe, with the
+    numbers of the unsanitized build of the same file."""
+    src = tmp_path / "m.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstdint>
+#include <cmath>
+#include <vector>
+#include "opv_offset_host.h"
+int main() {
+    std::vector<int16_t> iq(2 * 40000, 0);
+    for (int n = 0; n < 40000; ++n) iq[2 * n] = (int16_t)std::lrint(9000.0 * std::cos(2 * 3.14159265358979323846 * 36000.0 * n / 2168000.0 + 0.3));
+    const double e0 = opv_offset_candidate_energy(iq.data(), 1000, -1500.0), e1 = opv_offset_candidate_energy(iq.data(), 1000, 1500.0);
+    const double em = opv_offset_candidate_energy(iq.data(), 1000, 0.0);
+    double poly[19] = {0};
+    const double th = 2 * 3.14159265358979323846 * 1500.0 / 2168000.0;
+    poly[0] = em; poly[2] = (e0 - em) / (th * th);
+    double out[134]; uint32_t ties = 0;
+    const double est = opv_offset_decide_on_host(iq.data(), 1000, poly, out, &ties);
+    std::printf("%a %a %a %.1f %u %d\n", e0, e1, em, est, ties, (int)opv_offset_host_libm_matches_reference());
+    return 0;
+}
+''')
+    pkg = PKG / "csrc"
+    flags = {"asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], "tsan": ["-fsanitize=thread"]}[variant]
+    outs = []
+    for extra, exe in ((flags, tmp_path / "san"), ([], tmp_path / "plain")):
+        subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-I", str(pkg)] + extra + ["-o", str(exe), str(src), str(pkg / "opv_offset_host.cpp"),
+                        "-lpthread", "-lm"], check=True)
+        outs.append(run([str(exe)]).stdout.decode().split())
+    assert outs[0] == outs[1], outs
+    e0, e1, em, est, ties, probe = outs[0]
+    assert e0 == e1 and float.fromhex(e0) > float.fromhex(em) and est == "-1530.0" and int(ties) >= 2 and probe == "1"
