@@ -1990,11 +1990,18 @@ def test_every_tiny_tail_and_tiny_capture(amd, oracle, iq10, frontend):
 def test_random_call_sequences(amd, oracle, iq10, seed):
     """Randomised use of the boundary: pushes of random sizes to random streams (singly or batched), opv_process
     at random moments, pops of random streams in between, a staging buffer small enough to be compacted every
-    few chunks. Whatever the interleaving, each stream's frames, metadata and tracker events are the oracle's."""
+    few chunks. Odd seeds feed from PINNED host memory - batches then go through the gather kernel, a third of them through
+    opv_push_iq_batch_async with whatever call comes next (another push, opv_process, a pop, a reset) left to settle or order
+    it. Whatever the interleaving, each stream's frames, metadata and tracker events are the oracle's."""
     rng = np.random.default_rng(seed)
     S = 6
     caps = [impair(iq10, amp=float(rng.uniform(800, 6000)), f0_hz=float(rng.uniform(-1900, 1900)),
                    ebn0_db=float(rng.uniform(11, 22)), seed=seed * 50 + k) for k in range(S)]
+    src = caps
+    if seed % 2 == 1:
+        import torch
+        keep = [torch.from_numpy(np.ascontiguousarray(c)).pin_memory() for c in caps]
+        src = [t.numpy() for t in keep]
     d = amd.Demod(S, max_samples=3 * 86720 + 70000, streaming=True)
     if seed % 3 == 0 and not os.environ.get("OPV_NO_X4"):
         d.set_frontend(4 if seed % 2 else 16)
@@ -2020,9 +2027,11 @@ def test_random_call_sequences(amd, oracle, iq10, seed):
                 blks = []
                 for k in ks:
                     n = int(min(rng.integers(1, 50000), caps[k].size // 2 - at[k], 60000 - since[k]))
-                    blks.append(caps[k][2 * at[k]: 2 * (at[k] + n)]); at[k] += n; since[k] += n; unpopped[k] += n
+                    blks.append(src[k][2 * at[k]: 2 * (at[k] + n)]); at[k] += n; since[k] += n; unpopped[k] += n
                 if len(ks) == 1 and rng.integers(0, 2):
                     d.push(ks[0], blks[0])
+                elif src is not caps and rng.integers(0, 3) == 0:
+                    d.push_batch(ks, blks, wait=False)
                 else:
                     d.push_batch(ks, blks)
         if act in (6, 7):
