@@ -180,11 +180,8 @@ int opv_sync(opv_ctx* ctx);
  * 16 = sixteen streams per wavefront, one per DPP quad (fewest issued instructions per symbol and stream: 38 against 88 and 156;
  *      right from ~8 000 streams per context, where 16 per wave still put a wave on every second SIMD),
  * 0 = automatic (4 from 2049 streams per context, 16 from 8193; measured cross-overs on MI355X).
- * Comparison build only (make -C opv-cxx-demod_amd variants -> build/cmp/libopv_demod_hip.so; the product library answers
- * OPV_EINVAL): -1 = one wavefront per stream with the product + permlane-swap reductions (the default until the row-broadcast
- * reduction replaced it: 1041 against 880 cycles per symbol), -2 = TWO wavefronts per stream, one per feedback loop (exact,
- * 6 % slower than -1). Results do not depend on the mapping beyond the fp64 re-association level of the soft symbols (all
- * decisions identical; the tests run every mapping). */
+ * Anything else is OPV_EINVAL. Results do not depend on the mapping beyond the fp64 re-association level of the soft symbols
+ * (all decisions identical; the tests run every mapping and every launch shape against the oracle). */
 int opv_set_frontend(opv_ctx* ctx, int streams_per_wave);
 /* Name of the front-end kernel the LAST opv_process launched ("k_msk_frontend_rb", "..._rb_wg4", "k_msk_frontend_x4_wg4", "k_msk_frontend_x16_wg4", ...;
  * "" before the first round): what a profile or a bench line should be read against. No counterpart in the reference. */
@@ -264,7 +261,7 @@ int opv_offset_ties_on_host(opv_ctx* ctx);
 int opv_tap_wave_info(opv_ctx* ctx, int stream, uint64_t out[4]);
 
 /* Workgroups of each hot-path kernel the runtime can keep resident per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor), in the
- * order k_msk_frontend_rb, _rb_wg4, k_msk_frontend_x4, _x4_wg4, k_frame_decode, k_frame_scale. Diagnostic. */
+ * order k_msk_frontend_rb, _rb_wg4, k_msk_frontend_x16_wg4, k_msk_frontend_x4_wg4, k_frame_decode, k_frame_scale. Diagnostic. */
 int opv_tap_occupancy(opv_ctx* ctx, int out[6]);
 
 /* Stand-alone FrameDecoder::decode (src/opv-demod.cpp:854-898) on n_frames payloads of

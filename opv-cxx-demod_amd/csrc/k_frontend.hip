@@ -38,12 +38,7 @@
 //     correlations of both tones + the on-time sums P1..P4) as row partials in lane t = lane & 15, one all-reduce over
 //     the four rows completes them, v_mov_b64_dpp row_newbcast hands out what the loop filters need, the energies and
 //     the dominant-tone select are lane-parallel. 153 VALU instructions per symbol.
-//     Round-1 body (`symbol`, kernels k_msk_frontend / _wg4 / _dual, mapping -1 / -2): products per lane, then
-//     v_permlane32_swap / v_permlane16_swap (reduce-scatter, 2 steps) + DPP row rotations, result handed to every lane
-//     by v_readlane (no LDS scratch). The on-time gate goes first (4 values); it decides the soft value and the
-//     dominant tone, and only THEN do the lanes form their early/late products - for the dominant tone alone, so the
-//     second reduction also carries 4 values instead of 8. 197 VALU instructions per symbol.
-//     Either way the scalar loop filters run redundantly on all lanes (wave-uniform, no divergence).
+//     The scalar loop filters run redundantly on all lanes (wave-uniform, no divergence).
 //   * A LONE wave on a SIMD issues one instruction of ANY kind (VALU, SALU, LDS, s_nop, branch)
 //     every ~4.7 cycles and gains nothing from independent chains (scripts/microbench): the
 //     symbol rate is set by the instruction COUNT of the loop body. Hence: no per-symbol
@@ -88,11 +83,9 @@ constexpr uint32_t kAhead = 56;                 // highest tap is floor(pos) + 5
 static_assert((kRing & (kRing - 1)) == 0, "ring must be a power of two");
 
 // LDS map (bytes): WPB x (ring | guard), then ONE atan table shared by the workgroup's waves:
-//   row-broadcast body (k_msk_frontend_rb / _rb_wg4): 1025 rows x 4 doubles (opv_atan_table_q3r.inc: pi/4 + atan(q) around q = k/512,
-//     a cubic in q itself, 4e-14 rad: opv_atan2.h says why that is plenty) = 32 800 B -> 49 200 B for one wave, 98 400 B for four;
-//   round-1 body (k_msk_frontend / _wg4 / _dual): 33 rows x kTabRow doubles (c0..c8, pad) = 2 640 B -> 19 040 B / 68 240 B
+//   1025 rows x 4 doubles (opv_atan_table_q3r.inc: pi/4 + atan(q) around q = k/512, a cubic in q itself, 4e-14 rad:
+//   opv_atan2.h says why that is plenty) = 32 800 B -> 49 200 B for one wave, 98 400 B for four
 constexpr uint32_t kTabOff = kRingBytes + kGuardBytes;   // 16400
-constexpr uint32_t kTabRow = 10;
 static_assert(kTabOff % 16 == 0, "16-byte LDS alignment");
 
 typedef __attribute__((address_space(1))) double gdouble;
@@ -113,13 +106,6 @@ __device__ inline double swap16_add(double a, double b) {
     auto lo = __builtin_amdgcn_permlane16_swap((unsigned)dlo(a), (unsigned)dlo(b), false, false);
     auto hi = __builtin_amdgcn_permlane16_swap((unsigned)dhi(a), (unsigned)dhi(b), false, false);
     return mkd((int)hi[0], (int)lo[0]) + mkd((int)hi[1], (int)lo[1]);
-}
-template <int CTRL>
-__device__ inline double dpp_add(double v) {
-    // bound_ctrl:1 => no "old" operand to materialise (every lane of a row_ror is valid anyway)
-    const int lo = __builtin_amdgcn_mov_dpp(dlo(v), CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_mov_dpp(dhi(v), CTRL, 0xF, 0xF, true);
-    return v + mkd(hi, lo);
 }
 // v_mov_b64_dpp row_newbcast:N - lane N of every row of 16 to all lanes of that row (the one DPP control 64-bit operations
 // take). Through the builtin, so that hipcc sees the DPP hazards and schedules around them; every lane is written, `old`
@@ -232,42 +218,6 @@ __device__ __noinline__ double2 silence_pd(double dr, double di, PrevSums prv, b
 }  // namespace
 
 #include "opv_atan2.h"  // kOpvAtanTabQ3R (constant-memory image of the angle table) + the host statement of the routine
-#ifdef OPV_WITH_COMPARISON_MAPPINGS
-#include "../variants/opv_atan2_cmp.h"   // kOpvAtanTab: the 33-row table of the round-1 body (comparison build only)
-#endif
-
-// ---- two-waves-per-stream mapping (ROLE 1 / 2 of msk_frontend_body): hand-over slots behind the atan table -------
-[[maybe_unused]] constexpr uint32_t kXchgPos = 0;      // 2 x {double pos; uint32 tag; pad}: position of symbol `tag`, written by the timing wave
-constexpr uint32_t kXchgFo = 32;      // 2 x {double fo;  uint32 tag; pad}: frequency for symbol `tag`, written by the AFC wave
-[[maybe_unused]] constexpr uint32_t kXchgBytes = 64;
-[[maybe_unused]] constexpr uint32_t kPollLimit = 1u << 22;   // a wave that has polled this often gives up: nothing can hang
-
-#ifdef OPV_WITH_COMPARISON_MAPPINGS
-// Wait until the {value, tag} slot at LDS address `a` carries `want`: one scalar loop (tag first, then the value - LDS
-// reads of a wave return in order, so a matching tag guarantees the value written before it).
-__device__ inline void role_await(uint32_t a, uint32_t want, double& v, uint32_t& timeouts) {
-    uint32_t got_v, got_s, cnt;
-    double val;
-    asm volatile(
-        "s_mov_b32 %[cnt], 0\n"
-        "1:\n\t"
-        "ds_read_b32 %[gv], %[a] offset:8\n\t"
-        "ds_read_b64 %[val], %[a]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_readfirstlane_b32 %[gs], %[gv]\n\t"
-        "s_cmp_eq_u32 %[gs], %[want]\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "s_add_u32 %[cnt], %[cnt], 1\n\t"
-        "s_cmp_lt_u32 %[cnt], %[lim]\n\t"
-        "s_cbranch_scc1 1b\n"
-        "2:"
-        : [gv] "=&v"(got_v), [val] "=&v"(val), [gs] "=&s"(got_s), [cnt] "=&s"(cnt)
-        : [a] "v"(a), [want] "s"(want), [lim] "s"(kPollLimit)
-        : "memory", "scc");
-    timeouts |= (cnt >= kPollLimit) ? 1u : 0u;
-    v = val;
-}
-#endif
 
 // WPB = wavefronts (= streams) per workgroup. One wave per workgroup is the natural shape, but the dispatcher
 // places single-wave workgroups without regard to SIMDs: with 1024 of them on the chip's 1024 SIMDs, 88 SIMDs
@@ -276,50 +226,30 @@ __device__ inline void role_await(uint32_t a, uint32_t want, double& v, uint32_t
 // the kernel's duration. A 256-thread workgroup's four waves always land on the four SIMDs of one CU, so from 513
 // streams on the shim launches four streams per workgroup (k_msk_frontend_wg4). Waves of a workgroup share nothing
 // but the atan table.
-// ROLE 0: the whole demodulator on one wave. ROLE 1 / 2: the two-waves-per-stream mapping (k_msk_frontend_dual) - wave T
-// (1) runs the timing loop, wave F (2) the AFC; both form the taps and the on-time sums (identical operations on identical
-// bits), every statement below that belongs to the other loop is compiled out, and at the end of a symbol T publishes
-// pos(k+1), F publishes fo(k+1); each waits for the other's number where it first needs it. Tile staging is T's; its
-// events keep one symbol more margin so that F, at most one symbol behind, never reads a tile that has not landed or has
-// been recycled. STATUS: exact (tests/test_gpu_parity.py::test_comparison_mappings_are_exact) but 6 % SLOWER than
-// ROLE 0 (1111 vs 1043 cycles per symbol at 64 streams): each wave's LDS round trips and cross-lane hazard slots are no
-// longer filled by the other loop's arithmetic, and the partner is waited for once per symbol. It is
-// never selected automatically (opv_set_frontend(ctx, -2)).
-template <int WPB, int ROLE, int BODY = 0>
+// (A two-waves-per-stream mapping and the round-1 symbol body were measured against this one - 6 % and 25 % slower -
+// and removed in round 6: NOTEBOOK.md has the measurements, git the code.)
+template <int WPB>
 __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ streams, OpvGlobalCfg cfg, int n_streams,
                                                   unsigned char* lds_all) {
-    // BODY 0: products + permlane-swap reductions (`symbol`, round 1); 1: row-broadcast reduction (`symbol_r`, round 2)
-    constexpr bool RMAC = BODY != 0;
-    static_assert(!RMAC || ROLE == 0, "the row-broadcast reduction is a variant of the one-wave mapping");
-    constexpr bool kT = ROLE != 2;       // this wave runs the timing loop (and stages the tiles)
-    constexpr bool kF = ROLE != 1;       // this wave runs the AFC (and logs the soft symbols)
-    constexpr bool kDual = ROLE != 0;
     const int lane = threadIdx.x & 63;
-    const int wave = (kDual || WPB == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (a constant 0 lets the ring base fold into the tap address)
-    const int sidx = kDual ? (int)blockIdx.x : (int)blockIdx.x * WPB + wave;
+    const int wave = WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (a constant 0 lets the ring base fold into the tap address)
+    const int sidx = (int)blockIdx.x * WPB + wave;
     const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 
-    unsigned char* const lds = lds_all + wave * kTabOff;      // this wave's ring + guard (shared by T and F)
+    unsigned char* const lds = lds_all + wave * kTabOff;      // this wave's ring + guard
     const unsigned char* ringb = lds;
     double* atab = reinterpret_cast<double*>(lds_all + WPB * kTabOff);   // filled by the kernel wrapper, barrier included
     if (sidx >= n_streams) return;       // a last, partly filled workgroup
     OpvStream& st = streams[sidx];
 
     // ---- per-lane constants -------------------------------------------------------------
-    // RMAC: rows of 15 samples (lane 16 r + n <-> sample 15 r + n, n < 15; a row's last lane repeats its neighbour's
+    // rows of 15 samples (lane 16 r + n <-> sample 15 r + n, n < 15; a row's last lane repeats its neighbour's
     // sample and carries no weight), so that the 60 samples take 15 broadcast steps per row instead of 16
-    const int jsamp = RMAC ? lane - (lane >> 4) - ((lane & 15) == 15 ? 1 : 0) : lane;
+    const int jsamp = lane - (lane >> 4) - ((lane & 15) == 15 ? 1 : 0);
     const double kf = (double)(jsamp - 10);
     const double kfs = kf * kDeltaPerHz;
-    // T_1[i] = exp(-j 2 pi i / 160) = (cos(pi i/80), -sin(pi i/80)); zero outside a gate's window
-    [[maybe_unused]] double aE = 0, bE = 0, aO = 0, bO = 0, aL = 0, bL = 0;
-    if constexpr (!RMAC) {
-        double sn, cs;
-        if (lane < 40) { sincospi((double)lane / 80.0, &sn, &cs); aE = cs; bE = -sn; }
-        if (lane >= 10 && lane < 50) { sincospi((double)(lane - 10) / 80.0, &sn, &cs); aO = cs; bO = -sn; }
-        if (lane >= 20 && lane < 60) { sincospi((double)(lane - 20) / 80.0, &sn, &cs); aL = cs; bL = -sn; }
-    }
-    // RMAC: output t = lane & 15 of every row is one of the symbol's window sums, and wr[n] / wi[n] are the weights of
+    // T_1[i] = exp(-j 2 pi i / 160) = (a, b) = (cos(pi i/80), -sin(pi i/80)); zero outside a gate's window.
+    // Output t = lane & 15 of every row is one of the symbol's window sums, and wr[n] / wi[n] are the weights of
     // Re / Im Z of the row's n-th sample in it (see `symbol_r`). Correlations C_1 = sum Z conj(T_1[i]) = (sum Zr a + Zi b,
     // sum Zi a - Zr b), C_2 = sum Z T_1[i] = (sum Zr a - Zi b, sum Zi a + Zr b); Re in t, Im in t + 8:
     //   t = 0, 1   on-time correlation of tone 1 / tone 2 (S_1, S_2)                          (window j in [10, 50), i = j - 10)
@@ -327,8 +257,8 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     //                                                                                           late: j in [20, 60), i = j - 20)
     //   t = 6, 7, 14, 15   the on-time sums P1 = sum Zr a, P2 = sum Zi b, P3 = sum Zi a, P4 = sum Zr b
     //              (S_1 = (P1 + P2, P3 - P4), S_2 = (P1 - P2, P3 + P4): what the phase detector and the carry use)
-    [[maybe_unused]] double wr[15], wi[15];
-    if constexpr (RMAC) {
+    double wr[15], wi[15];
+    {
         const int row = lane >> 4, t = lane & 15, u = t & 7;
         const bool is_p = u >= 6, imag = t >= 8;
         const int gate = (u < 2 || is_p) ? 1 : ((u & 1) ? 2 : 0);  // 0 early, 1 on-time, 2 late (u = 2: E_1, 3: L_1, 4: E_2, 5: L_2)
@@ -358,7 +288,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     double kc_tiny = 1e-100;
     asm volatile("" : "+v"(kc_tiny));
     double kc_halfpi = 1.57079632679489661923, kc_32 = 32.0, kc_m1_32 = -1.0 / 32.0, kc_gain = st.afc_alpha * (kSymRate / kTwoPi);
-    // rows per unit of the angle table, its inverse, 1.5 * 2^52 + the row offset (row-broadcast body: the 1025 rows of opv_atan2_q3r)
+    // rows per unit of the angle table, its inverse, 1.5 * 2^52 + the row offset (the 1025 rows of opv_atan2_q3r)
     [[maybe_unused]] double kc_64 = 512.0, kc_m1_64 = -1.0 / 512.0, kc_magic = 6755399441055744.0 + 512.0;
     asm volatile("" : "+v"(kc_64), "+v"(kc_m1_64), "+v"(kc_magic));
     asm volatile("" : "+v"(kc_tfmax), "+v"(kc_beta), "+v"(kc_alpha), "+v"(kc_fomax), "+v"(kc_eps));
@@ -406,16 +336,6 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                      : "memory");
     };
     const uint32_t lds_base = uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds);
-    [[maybe_unused]] const uint32_t xchg = uni((uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(lds_all + WPB * kTabOff + 33 * kTabRow * 8));
-    [[maybe_unused]] uint32_t seq = 0, timeouts = 0;       // symbols of this launch so far; pos(seq) / fo(seq) carry that tag
-    [[maybe_unused]] auto publish = [&](uint32_t slot, double v, uint32_t tag) {   // value, then tag: every lane, same bytes
-        asm volatile("ds_write_b64 %0, %1\n\tds_write_b32 %0, %2 offset:8" : : "v"(xchg + slot + ((tag & 1u) << 4)), "v"(v), "v"(tag) : "memory");
-    };
-    [[maybe_unused]] auto await = [&](uint32_t slot, uint32_t tag, double& v) {
-#ifdef OPV_WITH_COMPARISON_MAPPINGS
-        role_await(xchg + slot + ((tag & 1u) << 4), uni(tag), v, timeouts);
-#endif
-    };
     auto issue_tile = [&](uint32_t t) {
         // tile t -> slot t&1: 8 wave instructions; an even tile's first 16 B are mirrored into the
         // guard behind the ring. The capture's last, incomplete 16 bytes (n_avail not a multiple
@@ -440,19 +360,12 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         }
     };
     // lowest sample any lane can touch at the first symbol of this launch
-    constexpr uint32_t kBackR = kBack + (kDual ? 44u : 0u), kAheadR = kAhead + (kDual ? 44u : 0u);   // dual: the other wave may be a symbol behind
-    uint32_t t_lo = (origin >= kBackR ? origin - kBackR : 0u) / kTile;
-    if constexpr (kT) {
-        issue_tile(t_lo);
-        issue_tile(t_lo + 1u);
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): both tiles (and the guard) landed
-    }
-    if constexpr (kDual) {
-        if constexpr (kF) publish(kXchgFo, st.freq_offset, 0u);   // T awaits fo(seq) at every symbol, the launch's first included
-        __syncthreads();                 // the first tiles before F's first tap
-    }
+    uint32_t t_lo = (origin >= kBack ? origin - kBack : 0u) / kTile;
+    issue_tile(t_lo);
+    issue_tile(t_lo + 1u);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): both tiles (and the guard) landed
     bool evt_issue = true;               // next tile event: request tile t_lo+2 (else: wait for the newest)
-    uint32_t next_evt = (t_lo + 1u) * kTile + kBackR;
+    uint32_t next_evt = (t_lo + 1u) * kTile + kBack;
 
     for (;;) {
         // ---- which demodulate() call comes next (ref :1026 / :1088 / :1173) ----------------
@@ -489,14 +402,14 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
                 if (evt_issue) {
                     // the lowest tap has left tile t_lo for good: refill its slot with tile
                     // t_lo+2 (asynchronous; first needed a whole tile = ~51 symbols from now)
-                    if constexpr (kT) issue_tile(t_lo + 2u);   // (F keeps the schedule only: same batches in both waves)
+                    issue_tile(t_lo + 2u);
                     ++t_lo;
                     evt_issue = false;
-                    next_evt = (t_lo + 1u) * kTile - kAheadR;
+                    next_evt = (t_lo + 1u) * kTile - kAhead;
                 } else {
-                    if constexpr (kT) __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): requested a tile ago, no stall
+                    __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): requested a tile ago, no stall
                     evt_issue = true;
-                    next_evt = (t_lo + 1u) * kTile + kBackR;
+                    next_evt = (t_lo + 1u) * kTile + kBack;
                 }
             }
             // j more symbols are safe iff gb + 42 j + 1 < next_evt and b + 1 + 42 j + 50 <= N
@@ -528,11 +441,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             fetch_read();
         };
 
-#ifdef OPV_WITH_COMPARISON_MAPPINGS
-#include "../variants/k_frontend_cmp_symbol.inc"   // `symbol`: the round-1 body + the two-waves-per-stream statements (comparison build only)
-#endif
-
-        // The same symbol with the ROW-BROADCAST reduction (RMAC; ROLE 0 only). gfx950's DP-ALU DPP form
+        // One symbol, with the ROW-BROADCAST reduction. gfx950's DP-ALU DPP form
         //   v_fmac_f64_dpp acc, src0 row_newbcast:n, src1      acc[l] += src0[row(l), lane n] * src1[l]
         // lets the 16 lanes of a row form 16 differently weighted sums of the row's samples, one broadcast step per
         // sample and component: 2 x 15 full-rate FMACs produce ALL twelve window sums of the symbol (on-time P1..P4, early
@@ -547,7 +456,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         // s_nop; every block here is therefore followed by a 32-bit instruction that was needed anyway, and the wait
         // states DPP reads / permlane swaps need behind a VALU write are filled with useful instructions, not s_nop.
         // (scripts/microbench/dpp64.hip has the instruction costs.)
-        [[maybe_unused]] auto symbol_r = [&](auto tag, PrevSums& cur, const PrevSums& prv) {
+        auto symbol_r = [&](auto tag, PrevSums& cur, const PrevSums& prv) {
             constexpr bool kFirst = decltype(tag)::first;
             constexpr bool kWide = decltype(tag)::wide;
             // The LO factor FIRST: it needs fo only, and its twelve instructions are the cover the tap read of the previous
@@ -640,7 +549,8 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             [[maybe_unused]] double pd = 0.0, cx = 0, cy = 0, sum = 1.0, dif = 0, dm_ = 1.0, ee, el;
             [[maybe_unused]] uint64_t zmask = 0;
             if constexpr (!kFirst) {
-                // phase detector operands: dom * conj(prev) (ref :299), see `symbol`
+                // phase detector operands: dom * conj(prev) (ref :299), prev advanced by one symbol's LO rotation
+                // (header: P_t = S_t (-/+ j) X[40]); sg picks the dominant tone's combination of the shared sums
                 const double dr = fma(sg, P2o, P1o), di = fma(-sg, P4o, P3o);
                 const double prs = fma(sg, prv.a, prv.b), pis = fma(sg, prv.c, -prv.d);
                 const double ar = fma(dr, prs, di * pis), ai = fma(di, prs, -(dr * pis));
@@ -735,15 +645,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             cur.a = P1o; cur.b = P2o; cur.c = P3o; cur.d = P4o;     // prev <- this symbol's on-time correlations (ref :309-310)
         };
 
-        auto sym = [&](auto tag, PrevSums& cur, const PrevSums& prv) {
-#ifdef OPV_WITH_COMPARISON_MAPPINGS
-            if constexpr (RMAC) symbol_r(tag, cur, prv);
-            else symbol(tag, cur, prv);
-#else
-            static_assert(RMAC, "the product build carries the row-broadcast body only");
-            symbol_r(tag, cur, prv);
-#endif
-        };
+        auto sym = [&](auto tag, PrevSums& cur, const PrevSums& prv) { symbol_r(tag, cur, prv); };
 
         if (uni_lt(pos + 40.0 + 10.0, Nd)) {               // ref :221
             (void)housekeeping(pos);
@@ -751,7 +653,7 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             sym(TagFirst{}, qp, qp);
             if (__builtin_expect(uni_lt(2000.0, fabs(fo)), 0) && uni_lt(pos + 40.0 + 10.0, Nd)) {
                 (void)housekeeping(pos);                   // an out-of-range -o is still in force for one more symbol
-                if constexpr (!kDual) fetch(pos, false);
+                fetch(pos, false);
                 sym(TagSecond{}, qq, qp);
                 qp = qq;
             }
@@ -761,19 +663,16 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
             // bookkeeping. Symbols go in pairs so that the "previous correlation" registers
             // alternate instead of being copied.
             while (uni_lt(pos + 40.0 + 10.0, Nd)) {        // ref :221
-                if constexpr (kDual) { if (__builtin_expect(timeouts != 0u, 0)) break; }   // the partner wave never came
                 uint32_t pairs = uni(housekeeping(pos)) >> 1;
-                if constexpr (!kDual) fetch(pos, false);   // (dual: the margins of the tile events make the early fetch final)
-                if constexpr (RMAC) {
-                    // four symbols per trip: a taken branch costs a lone wave 36 cycles (scripts/microbench/dpp64.hip, empty loop)
-                    for (uint32_t quads = pairs >> 1; quads != 0u; --quads) {
-                        sym(TagSteady{}, qq, qp);
-                        sym(TagSteady{}, qp, qq);
-                        sym(TagSteady{}, qq, qp);
-                        sym(TagSteady{}, qp, qq);
-                    }
-                    pairs &= 1u;
+                fetch(pos, false);
+                // four symbols per trip: a taken branch costs a lone wave 36 cycles (scripts/microbench/dpp64.hip, empty loop)
+                for (uint32_t quads = pairs >> 1; quads != 0u; --quads) {
+                    sym(TagSteady{}, qq, qp);
+                    sym(TagSteady{}, qp, qq);
+                    sym(TagSteady{}, qq, qp);
+                    sym(TagSteady{}, qp, qq);
                 }
+                pairs &= 1u;
                 for (; pairs != 0u; --pairs) {
                     sym(TagSteady{}, qq, qp);
                     sym(TagSteady{}, qp, qq);
@@ -784,15 +683,14 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         }
 
         // ---- end of this demodulate() call (ref :318-328, :1067-1076) ------------------------
-        if constexpr (kDual) { if (timeouts != 0u) { overflow = 2; break; } }   // give up loudly instead of hanging
         const uint32_t nsym_call = ((soft_off - soft_off0) & soft_bmask) >> 3;
         const uint32_t used = uni((uint32_t)pos);
         mu = pos - (double)used;
         const uint32_t leftover = N - used;
-        if (lane == 0) {                                   // chunk log is a ring (dual: each wave writes what it owns)
+        if (lane == 0) {                                   // chunk log is a ring
             double* c = st.chunk_log + 5 * (size_t)(n_chunks % st.cap_chunks);
-            if constexpr (kF) c[0] = fo;
-            if constexpr (kT) { c[1] = tf; c[2] = mu; c[3] = (double)leftover; c[4] = (double)nsym_call; }
+            c[0] = fo;
+            c[1] = tf; c[2] = mu; c[3] = (double)leftover; c[4] = (double)nsym_call;
         }
         ++n_chunks;
         n_soft += nsym_call;
@@ -802,13 +700,10 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
     }
 
     if (lane == 0) {
-        if constexpr (kF) {
-            st.freq_offset = fo;
-            st.p1r = qp.a; st.p1i = qp.b; st.p2r = qp.c; st.p2i = qp.d; st.x40c = qp.x40c; st.x40s = qp.x40s;
-            st.fo_sum = fo_sum;
-            st.edge_ties = edge_ties;
-        }
-        if constexpr (kT) {
+        st.freq_offset = fo;
+        st.p1r = qp.a; st.p1i = qp.b; st.p2r = qp.c; st.p2i = qp.d; st.x40c = qp.x40c; st.x40s = qp.x40s;
+        st.fo_sum = fo_sum;
+        st.edge_ties = edge_ties;
         st.timing_freq = tf; st.mu = mu;
         st.origin = origin; st.n_soft = n_soft; st.total_samples = total_samples;
         st.n_chunks = n_chunks; st.tail_done = tail_done; st.overflow = overflow;
@@ -820,36 +715,10 @@ __device__ __forceinline__ void msk_frontend_body(OpvStream* __restrict__ stream
         st.dbg_hw_id = hw; st.dbg_xcc_id = xcc;
         st.dbg_cycles = __builtin_amdgcn_s_memtime() - dbg_t0;
         st.dbg_ticks = __builtin_amdgcn_s_memrealtime() - dbg_r0;
-        }
     }
 }
 
-#ifdef OPV_WITH_COMPARISON_MAPPINGS   // the round-1 body under its two launch shapes (opv_set_frontend(ctx, -1)): comparison build only
-// atan table into LDS (shared by the workgroup's waves); the caller's barrier makes it visible
-template <int NT>
-__device__ __forceinline__ void load_atan_table(unsigned char* lds_tab) {
-    double* atab = reinterpret_cast<double*>(lds_tab);
-    for (int i = threadIdx.x; i < 33 * (int)kTabRow; i += NT) atab[i] = (&kOpvAtanTab[0][0])[i];
-}
-
-extern "C" __global__ __launch_bounds__(64) void k_msk_frontend(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
-                                                                 int n_streams) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[kTabOff + 33 * kTabRow * 8];
-    load_atan_table<64>(lds_all + kTabOff);
-    __syncthreads();
-    msk_frontend_body<1, 0>(streams, cfg, n_streams, lds_all);
-}
-// four streams per workgroup: one per SIMD of a CU by construction (see msk_frontend_body)
-extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_wg4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
-                                                                      int n_streams) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * kTabOff + 33 * kTabRow * 8];
-    load_atan_table<256>(lds_all + 4 * kTabOff);
-    __syncthreads();
-    msk_frontend_body<4, 0>(streams, cfg, n_streams, lds_all);
-}
-#endif
-// the product front-end: one wave per stream, row-broadcast reduction (msk_frontend_body<.., 0, 1>, `symbol_r`), one or four
-// waves per workgroup
+// the front-end kernels: one wave per stream, one or four waves (streams) per workgroup
 constexpr uint32_t kAtanQBytes = 1025 * 32;
 template <int NT>
 __device__ __forceinline__ void load_atan_table_q(unsigned char* lds_tab) {
@@ -861,24 +730,12 @@ extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_rb(OpvStream* __
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[kTabOff + kAtanQBytes];
     load_atan_table_q<64>(lds_all + kTabOff);
     __syncthreads();
-    msk_frontend_body<1, 0, 1>(streams, cfg, n_streams, lds_all);
+    msk_frontend_body<1>(streams, cfg, n_streams, lds_all);
 }
 extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_rb_wg4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
                                                                          int n_streams) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_all[4 * kTabOff + kAtanQBytes];
     load_atan_table_q<256>(lds_all + 4 * kTabOff);
     __syncthreads();
-    msk_frontend_body<4, 0, 1>(streams, cfg, n_streams, lds_all);
+    msk_frontend_body<4>(streams, cfg, n_streams, lds_all);
 }
-#ifdef OPV_WITH_COMPARISON_MAPPINGS
-// two waves per stream: wave 0 = timing loop (ROLE 1), wave 1 = AFC (ROLE 2), on two SIMDs of one CU
-extern "C" __global__ __launch_bounds__(128) void k_msk_frontend_dual(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
-                                                                       int n_streams) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_all[kTabOff + 33 * kTabRow * 8 + kXchgBytes];
-    load_atan_table<128>(lds_all + kTabOff);
-    if (threadIdx.x < kXchgBytes / 4) reinterpret_cast<uint32_t*>(lds_all + kTabOff + 33 * kTabRow * 8)[threadIdx.x] = 0xFFFFFFFFu;   // no tag yet
-    __syncthreads();
-    if (threadIdx.x < 64) msk_frontend_body<1, 1>(streams, cfg, n_streams, lds_all);
-    else msk_frontend_body<1, 2>(streams, cfg, n_streams, lds_all);
-}
-#endif

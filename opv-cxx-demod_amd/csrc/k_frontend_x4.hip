@@ -567,11 +567,8 @@ __device__ __forceinline__ void msk_frontend_x4_body(OpvStream* __restrict__ str
     }
 }
 
-extern "C" __global__ __launch_bounds__(64) void k_msk_frontend_x4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
-                                                                    int n_streams) {
-    msk_frontend_x4_body<1>(streams, cfg, n_streams);
-}
-// sixteen streams per workgroup: one wave per SIMD of a CU by construction
+// sixteen streams per workgroup: one wave per SIMD of a CU by construction. (A one-wave workgroup shape of this body existed
+// until round 6; it was reachable only by forcing this mapping beyond 8192 streams, where the automatic choice is sixteen per wave.)
 extern "C" __global__ __launch_bounds__(256) void k_msk_frontend_x4_wg4(OpvStream* __restrict__ streams, OpvGlobalCfg cfg,
                                                                         int n_streams) {
     msk_frontend_x4_body<4>(streams, cfg, n_streams);

@@ -6,8 +6,8 @@
 // below says why that is plenty). The routines here are the HOST statements of what the kernels evaluate inline on LDS /
 // constant-memory copies of the tables (tests/test_atan2_host.py builds this header for the host, against glibc).
 // Not handled here (callers do): x == y == 0 and non-finite inputs.
-// Elsewhere: the 33-row Taylor table of the round-1 body lives with the comparison build (variants/opv_atan2_cmp.h), the
-// 1025-row table in (k, h) form that the shipped one was derived from with the host tests (tests/atan/opv_atan2_q3.h).
+// Elsewhere: the 1025-row table in (k, h) form that the shipped one was derived from lives with the host tests
+// (tests/atan/opv_atan2_q3.h).
 #pragma once
 #include <math.h>
 

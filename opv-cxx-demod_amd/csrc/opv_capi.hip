@@ -23,14 +23,8 @@
 #include "opv_tx_internal.h"
 
 extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg, const double*, uint32_t*);
-#ifdef OPV_WITH_COMPARISON_MAPPINGS   // `make variants`: the round-1 body and the two-waves-per-stream mapping (opv_set_frontend -1 / -2)
-extern "C" __global__ void k_msk_frontend(OpvStream*, OpvGlobalCfg, int);
-extern "C" __global__ void k_msk_frontend_wg4(OpvStream*, OpvGlobalCfg, int);
-extern "C" __global__ void k_msk_frontend_dual(OpvStream*, OpvGlobalCfg, int);
-#endif
 extern "C" __global__ void k_msk_frontend_rb(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_rb_wg4(OpvStream*, OpvGlobalCfg, int);
-extern "C" __global__ void k_msk_frontend_x4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x16(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x16_wg4(OpvStream*, OpvGlobalCfg, int);
@@ -72,7 +66,6 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 // double up on SIMDs (k_frontend.hip: msk_frontend_body)
 constexpr uint64_t kScaleWaveMaxFrames = 4096;    // frames (upper estimate) per round up to which the scale pre-pass runs one wave per frame
 constexpr int kFrontendWg4MinStreams = 512;
-constexpr int kFrontendX4Wg4MaxStreams = 8192;   // 2048 waves = two 80 KB workgroups per CU; beyond that single-wave workgroups (20 KB)
 constexpr int kFrontendX16MinStreams = 8192;      // measured on MI355X: 8192 streams x 16 frames: four per wave 260 GS/s, sixteen per wave 247 (512 waves: half the SIMDs idle;
                                                   // with 7 frames per stream, bench.py's sweep, 221 / 255: the cross-over IS about 8192); 16 384 x 8: 187 / 478; 32 768 x 8: 204 / 574
 constexpr int kFrontendX16Wg8MinStreams = 16384;  // 1024 waves of sixteen streams = one per SIMD; beyond that eight waves (two per SIMD) per workgroup
@@ -869,26 +862,14 @@ extern "C" int opv_process(opv_ctx* c) {
         c->last_frontend = "k_coherent_frontend";
         k_coherent_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, 2.0 * zeta * wn / fsym, wn * wn / (fsym * fsym));
     }
-#ifdef OPV_WITH_COMPARISON_MAPPINGS
-    else if (c->frontend == -2) {                          // two waves per stream (opv_set_frontend(-2))
-        c->last_frontend = "k_msk_frontend_dual";
-        k_msk_frontend_dual<<<S, 128, 0, c->stream>>>(c->d_streams, g, S);
-    } else if (c->frontend == -1) {                        // one wave per stream, product + swap reductions (the round-1 body)
-        if (S > kFrontendWg4MinStreams) { c->last_frontend = "k_msk_frontend_wg4"; k_msk_frontend_wg4<<<(S + 3) / 4, 256, 0, c->stream>>>(c->d_streams, g, S); }
-        else { c->last_frontend = "k_msk_frontend"; k_msk_frontend<<<S, 64, 0, c->stream>>>(c->d_streams, g, S); }
-    }
-#endif
     else if (c->frontend == 16 || (c->frontend == 0 && S > kFrontendX16MinStreams)) {   // sixteen streams per wave (k_frontend_x16.hip): four waves (64 streams) per workgroup
         if (S > kFrontendX16Wg8MinStreams) { c->last_frontend = "k_msk_frontend_x16_wg8"; k_msk_frontend_x16_wg8<<<(S + 127) / 128, 512, 0, c->stream>>>(c->d_streams, g, S); }
         else if (S > 16) { c->last_frontend = "k_msk_frontend_x16_wg4"; k_msk_frontend_x16_wg4<<<(S + 63) / 64, 256, 0, c->stream>>>(c->d_streams, g, S); }
         else { c->last_frontend = "k_msk_frontend_x16"; k_msk_frontend_x16<<<1, 64, 0, c->stream>>>(c->d_streams, g, S); }
     }
-    else if (x4 && S <= kFrontendX4Wg4MaxStreams) {      // up to two waves per SIMD: four waves (16 streams) per workgroup
+    else if (x4) {                                        // four waves (16 streams) per workgroup, whatever the stream count (automatic: 2049..8192)
         c->last_frontend = "k_msk_frontend_x4_wg4";
         k_msk_frontend_x4_wg4<<<(S + 15) / 16, 256, 0, c->stream>>>(c->d_streams, g, S);
-    } else if (x4) {
-        c->last_frontend = "k_msk_frontend_x4";
-        k_msk_frontend_x4<<<(S + 3) / 4, 64, 0, c->stream>>>(c->d_streams, g, S);
     }
     // one wave per stream, row-broadcast reduction (k_frontend.hip: symbol_r). Its 272-278 registers allow one wave per SIMD;
     // four waves per workgroup (one per SIMD of a CU by construction) as soon as single-wave workgroups could double up
@@ -917,14 +898,7 @@ extern "C" int opv_process(opv_ctx* c) {
 
 extern "C" int opv_set_frontend(opv_ctx* c, int streams_per_wave) {
     if (!c) return fail(OPV_EINVAL, "null context");
-#ifdef OPV_WITH_COMPARISON_MAPPINGS
-    const bool cmp_ok = streams_per_wave == -1 || streams_per_wave == -2;
-#else
-    const bool cmp_ok = false;
-    if (streams_per_wave == -1 || streams_per_wave == -2)
-        return fail(OPV_EINVAL, "opv_set_frontend: the comparison mappings (-1, -2) are not part of this build (make variants)");
-#endif
-    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4 && streams_per_wave != 16 && !cmp_ok)
+    if (streams_per_wave != 0 && streams_per_wave != 1 && streams_per_wave != 4 && streams_per_wave != 16)
         return fail(OPV_EINVAL, "opv_set_frontend: 0 (automatic), 1, 4 or 16 streams per wave");
     c->frontend = streams_per_wave;
     return OPV_OK;
@@ -1169,7 +1143,7 @@ extern "C" int opv_tap_occupancy(opv_ctx* c, int out[6]) {
     if (!c || !out) return fail(OPV_EINVAL, "null argument");
     HIPCHK(hipSetDevice(c->cfg.device));
     const struct { const void* k; int threads; } ks[6] = {
-        {(const void*)k_msk_frontend_rb, 64}, {(const void*)k_msk_frontend_rb_wg4, 256}, {(const void*)k_msk_frontend_x4, 64},
+        {(const void*)k_msk_frontend_rb, 64}, {(const void*)k_msk_frontend_rb_wg4, 256}, {(const void*)k_msk_frontend_x16_wg4, 256},
         {(const void*)k_msk_frontend_x4_wg4, 256}, {(const void*)k_frame_decode, 64}, {(const void*)k_frame_scale, 64}};
     for (int i = 0; i < 6; ++i) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&out[i], ks[i].k, ks[i].threads, 0));
     return OPV_OK;

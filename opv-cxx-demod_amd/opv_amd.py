@@ -298,7 +298,7 @@ class Demod:
                        device, int(coherent), int(max_samples), float(pll_bw))
         self.h = C.c_void_p()
         _chk(lib().opv_create(C.byref(self.h), n_streams, C.byref(self.cfg)))
-        if os.environ.get("OPV_FRONTEND"):      # dev switch: run everything on one mapping (0 / 1 / 4 / -1 / -2)
+        if os.environ.get("OPV_FRONTEND"):      # dev switch: run everything on one mapping (0 / 1 / 4 / 16)
             self.set_frontend(int(os.environ["OPV_FRONTEND"]))
 
     def close(self):
@@ -416,7 +416,7 @@ class Demod:
         """workgroups per CU the runtime can keep resident, per hot-path kernel (opv_tap_occupancy)"""
         out = (C.c_int * 6)()
         _chk(lib().opv_tap_occupancy(self.h, out))
-        return dict(zip(("k_msk_frontend_rb", "k_msk_frontend_rb_wg4", "k_msk_frontend_x4", "k_msk_frontend_x4_wg4", "k_frame_decode",
+        return dict(zip(("k_msk_frontend_rb", "k_msk_frontend_rb_wg4", "k_msk_frontend_x16_wg4", "k_msk_frontend_x4_wg4", "k_frame_decode",
                          "k_frame_scale"), [int(v) for v in out]))
 
     def decode_payloads(self, soft, taps=False):

@@ -4,7 +4,7 @@ import numpy as np
 from amd_lib import load
 amd = load()
 d = amd.Demod(1, max_samples=1 << 20)
-print("occupancy [rb, rb_wg4, x4, x4_wg4, frame_decode, frame_scale]:", d.occupancy())
+print("occupancy [rb, rb_wg4, x16_wg4, x4_wg4, frame_decode, frame_scale]:", d.occupancy())
 rng = np.random.default_rng(3)
 base = rng.standard_normal((256, 2144)) * 2.4e11
 import ctypes as C

@@ -397,15 +397,14 @@ def test_rx_bridge_rejects_a_malformed_device_list(amd):
 
 
 def test_product_library_carries_the_product_front_ends_only():
-    """The shipped libopv_demod_hip.so exports the front-end kernels opv_process can launch in the product build - one wave
-    per stream with the row-broadcast reduction (two launch shapes), four streams per wave (two), sixteen per wave (three) -
-    and none of the comparison mappings (k_msk_frontend, _wg4, _dual: `make variants`, -DOPV_WITH_COMPARISON_MAPPINGS)."""
+    """The shipped libopv_demod_hip.so exports exactly the front-end kernels opv_process can launch - one wave per stream
+    (two launch shapes), four streams per wave (one), sixteen per wave (three); each has an oracle parity test."""
     import subprocess
     so = ROOT / "opv-cxx-demod_amd" / "libopv_demod_hip.so"
     out = subprocess.run(["nm", "-D", "--defined-only", str(so)], capture_output=True, text=True, check=True).stdout
     kernels = sorted(ln.split()[-1] for ln in out.splitlines() if ln.split()[-1].startswith("k_msk_frontend"))
     assert kernels == ["k_msk_frontend_rb", "k_msk_frontend_rb_wg4", "k_msk_frontend_x16", "k_msk_frontend_x16_wg4",
-                       "k_msk_frontend_x16_wg8", "k_msk_frontend_x4", "k_msk_frontend_x4_wg4"], kernels
+                       "k_msk_frontend_x16_wg8", "k_msk_frontend_x4_wg4"], kernels
 
 
 def test_cli_refuses_non_finite_flag_values():

@@ -366,9 +366,13 @@ def test_512_stream_context_vs_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("S", [522, 2060, 8200, 16400])
-def test_many_stream_contexts_on_the_automatic_mapping(S):
-    """16 400 streams: beyond 16 384 the sixteen-per-wave kernel runs EIGHT waves (128 streams, 8 rings + the table = 151 600 B of
+@pytest.mark.parametrize("S,forced", [(522, 0), (2060, 0), (8200, 0), (16400, 0), (8200, 4), (2060, 16), (600, 4)])
+def test_many_stream_contexts_on_the_automatic_mapping(S, forced):
+    """Every launch shape opv_process has for many streams, each against the oracle - decisions on EVERY stream, all soft symbols
+    (< 1e-9 of their mean) and the tracker's events on eight streams spread over the first, a middle and the last (partly filled)
+    workgroup. forced != 0: opv_set_frontend(forced) where the automatic choice would be another kernel - four per wave beyond
+    8192 streams (more 16-stream workgroups than the chip holds at once: the rest queue) and below 2049, sixteen per wave below 8193.
+    16 400 streams: beyond 16 384 the sixteen-per-wave kernel runs EIGHT waves (128 streams, 8 rings + the table = 151 600 B of
     LDS) per workgroup (k_msk_frontend_x16_wg8: 128 full workgroups + one with 16 streams, i.e. one busy wave and seven that have
     nothing to do). 8200 streams: beyond 8192 the shim takes sixteen streams per wave by itself (k_msk_frontend_x16_wg4: 128 full workgroups
     of 64 streams + one with 8, i.e. a wave with eight idle quads and three waves that have nothing to do). 522 streams: one wave per stream, FOUR waves per workgroup (k_msk_frontend_rb_wg4, from 513 streams; 130 full
@@ -383,16 +387,31 @@ def test_many_stream_contexts_on_the_automatic_mapping(S):
     dev = torch.device("cuda", 0)
     D, F = 24, 3
     n = amd.lib().opv_tx_modulated_samples(F)
+    from test_gpu_parity import events_match, soft_err
     dm = amd.Demod(S, max_samples=n + 64, streaming=True)
+    if forced:
+        dm.set_frontend(forced)
     d_iq, tx, n = workload.generate(amd, dm, torch, dev, range(D), F, 16.0)
     for k in range(S):
         dm.attach(k, d_iq[k % D].data_ptr(), n, eof=True)
     dm.process()
     dm.sync()
-    assert dm.frontend_kernel() == {522: "k_msk_frontend_rb_wg4", 2060: "k_msk_frontend_x4_wg4", 8200: "k_msk_frontend_x16_wg4", 16400: "k_msk_frontend_x16_wg8"}[S] or os.environ.get("OPV_FRONTEND")
+    want = {(522, 0): "k_msk_frontend_rb_wg4", (2060, 0): "k_msk_frontend_x4_wg4", (8200, 0): "k_msk_frontend_x16_wg4", (16400, 0): "k_msk_frontend_x16_wg8",
+            (8200, 4): "k_msk_frontend_x4_wg4", (2060, 16): "k_msk_frontend_x16_wg4", (600, 4): "k_msk_frontend_x4_wg4"}[(S, forced)]
+    assert dm.frontend_kernel() == want or (not forced and os.environ.get("OPV_FRONTEND"))
     host = d_iq.cpu().numpy()
     o = Oracle()
     exp = [o.receive(host[j], streaming=True, want_soft=False) for j in range(D)]
+    # first workgroup, a middle one, the last (partly filled) one: all soft symbols and the tracker's lines
+    picks = [0, 1, 2, S // 2, S // 2 + 1, S - 3, S - 2, S - 1]
+    worst = 0.0
+    for k in picks:
+        e = o.receive(host[k % D], streaming=True)
+        a, _ = soft_err(dm.soft(k), e["soft"])
+        worst = max(worst, a)
+        assert a < 1e-9, (k, a)
+        events_match(amd, dm.pop_events(k), e["events"])
+    print(f"{want} at {S} streams: soft max|d|/mean|soft| over streams {picks} = {worst:.2e}")
     for k in range(S):
         e = exp[k % D]
         fr, meta = dm.pop_frames(k)

@@ -172,54 +172,14 @@ def test_afc_alpha_flag(amd, oracle, iq10):
     d.close()
 
 
-def comparison_mappings_built(amd):
-    """opv_set_frontend(ctx, -1 / -2) exist only in the comparison build (make variants -> build/cmp/libopv_demod_hip.so, loaded through
-    OPV_LIB); the product library answers OPV_EINVAL"""
-    d = amd.Demod(1, max_samples=1 << 16, streaming=True)
-    try:
-        d.set_frontend(-1)
-        return True
-    except amd.OpvError as e:
-        assert "not part of this build" in str(e)
-        return False
-    finally:
-        d.close()
-
-
 def test_set_frontend_accepts_the_documented_mappings_only(amd):
-    """opv_set_frontend: 0 (automatic), 1, 4, 16 (include/opv_demod.h), and -1, -2 in the comparison build only; anything else is
-    OPV_EINVAL with a message."""
-    cmp_build = comparison_mappings_built(amd)
+    """opv_set_frontend: 0 (automatic), 1, 4, 16 (include/opv_demod.h); anything else is OPV_EINVAL with a message."""
     d = amd.Demod(1, max_samples=1 << 16, streaming=True)
-    for ok in (0, 1, 4, 16) + ((-1, -2) if cmp_build else ()) + (0,):
+    for ok in (0, 1, 4, 16, 0):
         d.set_frontend(ok)
-    for bad in (2, 3, -3, 8, 64) + (() if cmp_build else (-1, -2)):
+    for bad in (2, 3, -1, -2, -3, 8, 64):
         with pytest.raises(amd.OpvError, match="opv_set_frontend"):
             d.set_frontend(bad)
-    d.close()
-
-
-@pytest.mark.parametrize("mapping", [-2, -1])
-def test_comparison_mappings_are_exact(amd, oracle, iq10, iq100, mapping):
-    """The two one-stream mappings kept for comparison, never selected automatically. opv_set_frontend(-2): the timing loop
-    and the AFC on two wavefronts that exchange pos / fo through LDS every symbol (k_msk_frontend_dual = ROLE 1 / 2 of
-    csrc/k_frontend.hip's body). opv_set_frontend(-1): one wavefront per stream with the product + permlane-swap reductions
-    (`symbol`; the default mapping 1 is the row-broadcast reduction `symbol_r`). Same bar as the other mappings: clean,
-    offset + noise, an out-of-range -o, ragged lengths, -s and batch, several streams in one context."""
-    if not comparison_mappings_built(amd):
-        pytest.skip("the product library carries no comparison mappings (make variants; OPV_LIB=.../build/cmp/libopv_demod_hip.so)")
-    caps = [iq10, impair(iq10, amp=3000.0, f0_hz=-1700.0, ebn0_db=9.0, seed=3), impair(iq100[: 2 * 40 * 86720], amp=2000.0, f0_hz=900.0, ebn0_db=14.0, seed=8),
-            iq10[: 2 * 123457], iq10[: 2 * 86719], np.zeros(2 * 90000, np.int16)]
-    for streaming in (True, False):
-        d = amd.Demod(len(caps), max_samples=max(c.size for c in caps) // 2 + 64, streaming=streaming)
-        d.set_frontend(mapping)
-        got = d.receive(caps)
-        d.close()
-        for k, x in enumerate(caps):
-            check_stream(amd, got[k], oracle.receive(x, streaming=streaming), f"mapping {mapping} stream {k} streaming={streaming}")
-    d = amd.Demod(1, max_samples=iq10.size // 2 + 64, streaming=True, init_offset=150000.0, afc_alpha=0.01)
-    d.set_frontend(mapping)
-    check_stream(amd, d.receive([iq10])[0], oracle.receive(iq10, streaming=True, init_offset=150000.0, afc_alpha=0.01), f"mapping {mapping} -o 150000")
     d.close()
 
 
@@ -1626,7 +1586,7 @@ def test_channel_accidents(amd, oracle):
     assert {1, 2, 3, 4, 5} <= kinds, kinds               # acquisitions, locks, sync OK, misses and a lost lock all occurred
 
 
-@pytest.mark.parametrize("order", [[0, 4, 1, -1, 16, 0], [16, 0, -2, 1, 4, 16]])
+@pytest.mark.parametrize("order", [[0, 4, 1, 16, 1, 0], [16, 0, 4, 1, 4, 16]])
 def test_mapping_switched_between_rounds(amd, oracle, order):
     """opv_set_frontend between two opv_process calls of running streams: every mapping reads and leaves the same per-stream
     carry (OpvStream), so a context may change its mapping at any round boundary - six noisy streams pushed in six pieces, a
@@ -1636,8 +1596,6 @@ def test_mapping_switched_between_rounds(amd, oracle, order):
                    f0_hz=float(rng.uniform(-1500, 1500)), ebn0_db=float(rng.uniform(12, 20)), seed=50 + k) for k in range(6)]
     n = caps[0].size // 2
     cuts = [0, n // 6, n // 3, n // 2, 2 * n // 3, 5 * n // 6, n]
-    if not comparison_mappings_built(amd):
-        order = [m if m >= 0 else 1 for m in order]      # the product library: mappings 0 / 1 / 4 only
     d = amd.Demod(6, max_samples=n + 64, streaming=True)
     for i, m in enumerate(order):
         d.set_frontend(m)
@@ -1660,7 +1618,7 @@ def test_mapping_switched_between_rounds(amd, oracle, order):
 
 @pytest.mark.parametrize("spw", [4, 16])
 def test_several_streams_per_wave_mappings(amd, oracle, iq10, iq100, spw):
-    """k_msk_frontend_x4 (four streams per wavefront, the mapping the shim picks from 2049 streams) and k_msk_frontend_x16
+    """k_msk_frontend_x4_wg4 (four streams per wavefront, the mapping the shim picks from 2049 streams) and k_msk_frontend_x16 / _x16_wg4
     (sixteen per wavefront, one per DPP quad: from 8193 streams) on the cases that exercise their per-row machinery: rows with
     different chunk schedules (clock error, truncation), idle rows (stream count not a multiple of 4 / 16), the first-symbol
     early-gate clamp, the end-of-capture partial block, digital-silence gaps, batch mode, incremental pushes."""
@@ -1679,6 +1637,7 @@ def test_several_streams_per_wave_mappings(amd, oracle, iq10, iq100, spw):
         d = amd.Demod(len(caps), max_samples=nmax + 64, streaming=streaming)
         d.set_frontend(spw)
         got = d.receive(caps)
+        assert d.frontend_kernel() == {4: "k_msk_frontend_x4_wg4", 16: "k_msk_frontend_x16"}[spw]   # 13 streams: sixteen per wave = ONE wave
         for k, x in enumerate(caps):
             check_stream(amd, got[k], oracle.receive(x, streaming=streaming), f"x{spw} stream {k} streaming={streaming}")
         d.close()
@@ -1697,6 +1656,7 @@ def test_several_streams_per_wave_mappings(amd, oracle, iq10, iq100, spw):
     d = amd.Demod(len(lens), max_samples=100000, streaming=True)
     d.set_frontend(spw)
     got = d.receive([iq10[: 2 * n] for n in lens])
+    assert d.frontend_kernel() == {4: "k_msk_frontend_x4_wg4", 16: "k_msk_frontend_x16_wg4"}[spw]  # 45 streams
     d.close()
     for n, g1 in zip(lens, got):
         e = oracle.receive(iq10[: 2 * n], streaming=True)
