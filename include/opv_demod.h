@@ -20,7 +20,10 @@
 extern "C" {
 #endif
 
-#define OPV_ABI_VERSION 6   /* 6: offset-search near-ties are decided with the HOST's libm (opv_offset_ties_on_host), one host wait in the round
+#define OPV_ABI_VERSION 7   /* 7: opv_process never waits on the host again - the host-libm decision of offset-search near-ties runs as a host
+                               function IN STREAM ORDER between the search and the front-end (+ opv_offset_ties_decided_on_host); opv_set_frontend
+                               takes 0 / 1 / 4 / 16 only (the comparison mappings are gone); opv_tap_occupancy's third entry is k_msk_frontend_x16_wg4;
+                               6: offset-search near-ties are decided with the HOST's libm (opv_offset_ties_on_host), one host wait in the round
                                in which a stream's search runs; + opv_push_iq_batch_async / opv_push_wait; opv_push_iq_batch moves blocks in
                                pinned host memory with one gather kernel;
                                5: opv_set_frontend takes 16 (sixteen streams per wavefront; automatic from 8193 streams) and answers OPV_EINVAL to
@@ -121,7 +124,8 @@ typedef struct opv_stream_state {
     int32_t offset_ties;      /* offset-search candidates that were within 1e-11 (relative energy) of the winner and were
                                  therefore re-evaluated in the reference's own order of operations (estimate_offset :143-159): on
                                  the device, and once more on the host with the host's sin / cos (the reference's libm) if two of
-                                 them are then still within 2e-13 of each other and opv_offset_ties_on_host() is 1 */
+                                 them are then still within 2e-13 of each other and opv_offset_ties_on_host() is 1. Both bands are
+                                 scaled by the input's power where the correlation is weak against it (csrc/k_offset_search.hip) */
 } opv_stream_state;
 
 typedef struct opv_ctx opv_ctx;
@@ -169,9 +173,9 @@ int opv_attach_device_iq(opv_ctx* ctx, int stream, const int16_t* d_iq, size_t n
 /* Runs the hot path on everything that is ready, for all streams, in four launches on the
  * context's HIP stream: offset search (estimate_offset :131-202), MSK front-end
  * (demodulate :206-329 incl. the chunker :1026-1076), sync tracker (:615-736) and frame
- * decode (FrameDecoder::decode :854-898). Asynchronous; opv_sync waits. (One host wait inside: in the round in which a stream's
- * offset search runs - its first full chunk, or EOF in batch mode - the call waits for that one kernel, because a search whose
- * candidates tie in the last places of sin / cos is decided with the host's libm before the front-end starts.) */
+ * decode (FrameDecoder::decode :854-898). Asynchronous in every round; opv_sync waits. (A search whose candidates tie in the
+ * last places of sin / cos is decided with the host's libm before the front-end starts - by a host function enqueued on the
+ * context's stream between the two kernels, not by the caller: see opv_offset_ties_on_host.) */
 int opv_process(opv_ctx* ctx);
 int opv_sync(opv_ctx* ctx);
 /* Stream-to-wavefront mapping of the front-end kernel (no counterpart in the reference, which is one thread
@@ -253,6 +257,9 @@ int opv_tap_offset_energies(opv_ctx* ctx, int stream, double* out134);
  * 0 = the device's sincos (another libm on the host, or OPV_OFFSET_DISTRUST_LIBM set): still the reference's order of
  * operations, counted in offset_ties, but an exact tie is then decided by a different libm than the reference's. */
 int opv_offset_ties_on_host(opv_ctx* ctx);
+/* Streams whose tie the host has decided so far in this context (they are decided in stream order behind their search kernel,
+ * opv_process does not wait for them: the number is final for a round after opv_sync). Diagnostic. */
+uint64_t opv_offset_ties_decided_on_host(opv_ctx* ctx);
 
 /* Where and how fast the wavefront that served `stream` ran in the LAST front-end launch (with four streams per
  * wave, the four share these numbers): out[0] = HW_REG_HW_ID, out[1] = HW_REG_XCC_ID, out[2] = shader-clock cycles (s_memtime) and

@@ -30,12 +30,22 @@
 // re-evaluations is reported (opv_stream_state.offset_ties).
 // That last band is closed on the HOST: a stream on which two RE-EVALUATED energies are still within kHostRel = 2e-13 of each
 // other (exact ties included: a real-valued capture) puts its index on `tie_list` and leaves its 19 polynomial coefficients in
-// OpvStream.est_poly; opv_process (opv_capi.hip) then repeats the decision for that stream with the contenders evaluated by
-// opv_offset_candidate_energy (opv_offset_host.cpp) - the reference's loop on the reference's own libm - before the
-// front-end is launched. Re-evaluated contenders further apart than that are decided here: sin / cos cannot move them past
-// each other (bound at kHostRel). Why not every guarded stream: a candidate costs the host 160 000 sin / cos, and a context
-// of 32 768 streams has a dozen guarded ones. The device's own decision stands throughout when the host's libm does not
-// reproduce the pinned energy (tie_list == nullptr then).
+// OpvStream.est_poly. Behind the search, in stream order and without a host wait (opv_capi.hip: opv_process), k_tie_collect
+// copies what the decision needs (coefficients, window count, the first <= 40 000 samples) into pinned host memory, a host
+// function (hipLaunchHostFunc) repeats the decision with the contenders evaluated by opv_offset_candidate_energy
+// (opv_offset_host.cpp) - the reference's loop on the reference's own libm - and k_tie_apply carries the estimate, the energies
+// tap and the tie count into the stream's context before the front-end reads them. Re-evaluated contenders further apart than
+// that are decided here: sin / cos cannot move them past each other (bound at kHostRel). Why not every guarded stream: a
+// candidate costs the host 160 000 sin / cos, and a context of 32 768 streams has a dozen guarded ones. The device's own
+// decision stands throughout when the host's libm does not reproduce the pinned energy (tie_list == nullptr then).
+//
+// Both bands are RELATIVE TO WHAT THE ERRORS SCALE WITH, which is not the energy alone: a correlation c = sum x conj(lo) over a
+// window carries an absolute error ~ eps sum |x|, so the energy E = sum |c|^2 carries ~ 2 eps sqrt(E) sqrt(40 P), P = sum |x|^2
+// over the samples used (Cauchy-Schwarz over taps and windows). For a signal the tones match, E ~ 40 P and that IS eps E; for
+// an input whose correlation is weak against its power (an out-of-band tone, an interferer, noise on a DC offset) it is
+// larger by sqrt(40 P / E). `near` below therefore accepts a gap d when d <= rel x E or d^2 <= rel^2 x 40 P E - products and
+// one subtraction, no square root, so that the host's restatement (opv_offset_host.cpp) reaches the same verdicts bit for bit.
+// P is an exact integer in fp64 (<= 80 000 x 2^31 < 2^53), whatever the order of summation.
 //
 // Roofline: 160 000 B read per stream, once. Compute: see above; no MFMA (the contraction is 40 x 40 per
 // window with weights that differ per tap - a GEMM only in name, and fp64).
@@ -56,6 +66,12 @@ constexpr double kTieRel = 1e-11;                        // "not clearly below t
 // products per window, the windows' errors added up without cancellation credit). Contenders that are still within kHostRel of
 // the best re-evaluated energy - 20x that bound - go to the host, whose libm IS the reference's; all others are decided here.
 constexpr double kHostRel = 2e-13;
+
+// is `e` within `rel` of `top` (>= e) on the scale the errors of both have? (see the header: power-scaled band)
+__device__ inline bool near(double top, double e, double rel, double power) {
+    const double d = top - e;
+    return d <= rel * top || d * d <= (rel * rel * 40.0) * power * top;
+}
 
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -141,7 +157,8 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
     __shared__ double s_poly[2 * kK - 1];
     __shared__ double s_e[134];
     __shared__ double s_scratch[3000];       // exact_energy: 2 x 1000 window-start phases + 1000 window energies
-    __shared__ double s_best_e, s_best, s_fine;
+    __shared__ double s_best_e, s_best, s_fine, s_power;
+    __shared__ double s_pw[4];
     __shared__ int s_ties, s_host;
     __shared__ unsigned char s_play[134];
 
@@ -151,6 +168,7 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
     for (int k = 0; k < kK; ++k) ed[k] = 0.0;
 #pragma unroll
     for (int p = 0; p < 2 * kK - 1; ++p) eo[p] = 0.0;
+    double pw = 0.0;                         // sum |x|^2 over this thread's windows (exact: integers below 2^53)
     const int4* iq4 = reinterpret_cast<const int4*>(st.iq);
     for (int sym = tid; sym < nsym; sym += 256) {
         // A = sum xr cos w_k, B = sum xi cos w_k, C = sum xi sin w_k, D = sum xr sin w_k
@@ -165,6 +183,7 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
             for (int j = 0; j < 4; ++j) {
                 const double xr = (double)(int)(short)(w[j] & 0xFFFF);
                 const double xi = (double)(w[j] >> 16);
+                pw = fma(xr, xr, fma(xi, xi, pw));
                 const double* wt = wtab + (size_t)(4 * q + j) * (2 * kK);   // wave-uniform address: scalar loads
 #pragma unroll
                 for (int k = 0; k < kK; ++k) {
@@ -207,10 +226,14 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
         v = wave_sum(v);
         if ((tid & 63) == 0) s_red[tid >> 6][p] = v;
     }
+    pw = wave_sum(pw);
+    if ((tid & 63) == 0) s_pw[tid >> 6] = pw;
     if (tid == 0) { s_best_e = 0.0; s_best = 0.0; s_fine = 0.0; s_ties = 0; s_host = 0; }
     __syncthreads();
     if (tid < 2 * kK - 1) st.est_poly[tid] = s_poly[tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+    if (tid == 0) st.est_power = s_power = (s_pw[0] + s_pw[1]) + (s_pw[2] + s_pw[3]);
     __syncthreads();
+    const double power = s_power;
     auto poly_energy = [&](double offset) {
         const double th = kTwoPi * offset / kFs;
         double e = s_poly[2 * kK - 2];
@@ -219,22 +242,21 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
         return e;
     };
     // Decide among candidates [c0, c1) the way the reference's loop does (strict '>' against the running best),
-    // after re-evaluating in its own order every candidate that is within kTieRel (1e-11) of the best energy in play
-    // (the running best included) unless the winner is clear.
+    // after re-evaluating in its own order every candidate that is within kTieRel (1e-11, power-scaled: `near`) of the
+    // best energy in play (the running best included) unless the winner is clear.
     auto decide = [&](int c0, int c1, double base_offset, double step, bool fine) {
         if (tid >= c0 && tid < c1) s_e[tid] = poly_energy(base_offset + step * (double)(tid - c0));
         __syncthreads();
         double top = s_best_e;
         for (int c = c0; c < c1; ++c) top = fmax(top, s_e[c]);
         if (top > 0.0) {
-            const double bar = top * (1.0 - kTieRel);
             // (the fine candidate AT the coarse winner's offset repeats its evaluation: identical by construction,
             // here as in the reference, and never '>' - it is no contender)
-            auto in_play = [&](int c) { return s_e[c] >= bar && !(fine && base_offset + step * (double)(c - c0) == s_best); };
-            int contenders = (fine && s_best_e >= bar) ? 1 : 0;   // the coarse winner defends its energy
+            auto in_play = [&](int c) { return near(top, s_e[c], kTieRel, power) && !(fine && base_offset + step * (double)(c - c0) == s_best); };
+            const bool defend = fine && near(top, s_best_e, kTieRel, power);   // the coarse winner defends its energy
+            int contenders = defend ? 1 : 0;
             for (int c = c0; c < c1; ++c) contenders += in_play(c);
             if (contenders > 1) {                         // workgroup-uniform: every thread sees the same LDS values
-                const bool defend = fine && s_best_e >= bar;
                 for (int c = c0; c < c1; ++c) {
                     const bool play = in_play(c);
                     if (tid == 0) s_play[c] = play ? 1 : 0;
@@ -254,8 +276,8 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
                     double m = defend ? s_best_e : 0.0;
                     for (int c = c0; c < c1; ++c)
                         if (s_play[c]) m = fmax(m, s_e[c]);
-                    int close = (defend && s_best_e >= m * (1.0 - kHostRel)) ? 1 : 0;
-                    for (int c = c0; c < c1; ++c) close += (s_play[c] && s_e[c] >= m * (1.0 - kHostRel)) ? 1 : 0;
+                    int close = (defend && near(m, s_best_e, kHostRel, power)) ? 1 : 0;
+                    for (int c = c0; c < c1; ++c) close += (s_play[c] && near(m, s_e[c], kHostRel, power)) ? 1 : 0;
                     if (close > 1) s_host = 1;
                 }
                 __syncthreads();
@@ -286,5 +308,39 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
         st.est_nsym = (uint32_t)nsym;
         st.first_chunk_done = 1;
         if (s_host && tie_list) tie_list[1 + atomicAdd(&tie_list[0], 1u)] = blockIdx.x;   // (capacity: one entry per stream)
+    }
+}
+
+// ---- the host's tie decision, in stream order (see the header; opv_capi.hip enqueues collect -> host function -> apply) -------
+// Pass `pass` serves entries [pass * slots, (pass + 1) * slots) of the tie list: one workgroup per slot copies the stream's
+// polynomial, power, window count and first nsym x 40 samples into pinned host memory (16 B per lane over PCIe).
+extern "C" __global__ __launch_bounds__(256) void k_tie_collect(const OpvStream* __restrict__ streams, const uint32_t* __restrict__ tie_list,
+                                                                 uint32_t pass, uint32_t slots, OpvTieStage* __restrict__ stage) {
+    const uint32_t listed = tie_list[0], first = pass * slots;
+    const uint32_t n = listed > first ? (listed - first < slots ? listed - first : slots) : 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stage->n = n; stage->listed = listed; }
+    if (blockIdx.x >= n) return;
+    const uint32_t s = tie_list[1 + first + blockIdx.x];
+    const OpvStream& st = streams[s];
+    OpvTieSlot& sl = stage->slot[blockIdx.x];
+    const uint32_t nsym = st.est_nsym <= 1000u ? st.est_nsym : 1000u;
+    if (threadIdx.x == 0) { sl.stream = s; sl.nsym = nsym; sl.power = st.est_power; sl.ties = 0; sl.est = st.est_offset; }
+    if (threadIdx.x < 2 * kK - 1) sl.poly[threadIdx.x] = st.est_poly[threadIdx.x];
+    const int4* src = reinterpret_cast<const int4*>(st.iq);
+    int4* dst = reinterpret_cast<int4*>(sl.iq);
+    for (uint32_t i = threadIdx.x; i < nsym * (OPV_SPS / 4); i += 256) dst[i] = src[i];
+}
+// What the host function left in the slots: estimate, tie count and the energies tap of each decided stream (ties == 0: the
+// host found nothing to re-evaluate - the device's decision stands).
+extern "C" __global__ __launch_bounds__(192) void k_tie_apply(OpvStream* __restrict__ streams, const OpvTieStage* __restrict__ stage, uint32_t slots, int n_streams) {
+    const uint32_t n = stage->n < slots ? stage->n : slots;
+    if (blockIdx.x >= n) return;
+    const OpvTieSlot& sl = stage->slot[blockIdx.x];
+    if (sl.ties == 0 || sl.stream >= (uint32_t)n_streams) return;
+    OpvStream& st = streams[sl.stream];
+    if (threadIdx.x < 134) st.energies[threadIdx.x] = sl.energies[threadIdx.x];
+    if (threadIdx.x == 0) {
+        st.freq_offset = st.est_offset = sl.est;      // demod.set_freq_offset(est) (ref :1033 / :1167)
+        st.est_ties = sl.ties;
     }
 }

@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <atomic>
+
 #include <climits>
 #include <cstddef>
 #include <cmath>
@@ -23,6 +25,8 @@
 #include "opv_tx_internal.h"
 
 extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg, const double*, uint32_t*);
+extern "C" __global__ void k_tie_collect(const OpvStream*, const uint32_t*, uint32_t, uint32_t, OpvTieStage*);
+extern "C" __global__ void k_tie_apply(OpvStream*, const OpvTieStage*, uint32_t, int);
 extern "C" __global__ void k_msk_frontend_rb(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_rb_wg4(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_x4_wg4(OpvStream*, OpvGlobalCfg, int);
@@ -218,12 +222,17 @@ struct opv_ctx {
     double* d_fscale = nullptr;
     int32_t* d_counts = nullptr;
     double* d_offs_wtab = nullptr;      // k_offset_search's moment weights: [40 taps][cos, sin][OPV_OFFS_TERMS]
-    // offset-search ties are decided with the HOST's libm (opv_offset_host.cpp): streams whose search re-evaluated a candidate
-    // put themselves on d_tie_list ([0] = count, then indices); opv_process reads it behind the search, before the front-end
+    // offset-search ties are decided with the HOST's libm (opv_offset_host.cpp), in stream order: streams whose search could not
+    // decide put themselves on d_tie_list ([0] = count, then indices); behind the search opv_process enqueues, per pass of
+    // tie_slots streams, k_tie_collect -> a host function -> k_tie_apply (TieWork below), and the front-end behind those
     uint32_t* d_tie_list = nullptr;
-    uint32_t* h_tie_list = nullptr;     // pinned, 1 + n_streams words
     bool host_ties = false;             // the host's libm reproduces the pinned reference energy (probed at opv_create)
-    std::vector<int16_t> tie_iq;        // <= 40 000 samples of the stream being decided
+    struct TieWork {                    // what the host function gets: stable for the context's life (opv_destroy drains the stream first)
+        OpvTieStage* stage = nullptr;   // pinned: header + tie_slots slots
+        uint32_t slots = 0;
+        std::atomic<uint64_t> decided{0};   // streams the host has decided so far (opv_offset_ties_decided_on_host)
+    } tie;
+    std::vector<int> search_now;        // streams whose offset search can run in the round being enqueued
     // opv_push_iq_batch: the table of the gather kernel / of the batched compaction, in pinned memory (the kernels read it in place)
     void* h_bulk_tab = nullptr;
     size_t bulk_tab_bytes = 0;
@@ -426,7 +435,9 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
     c->host_ties = opv_offset_host_libm_matches_reference() && !std::getenv("OPV_OFFSET_DISTRUST_LIBM");   // (test hook: the device-sincos path)
     if (c->host_ties) {
         HIPCHK_C(hipMalloc(&c->d_tie_list, sizeof(uint32_t) * (S + 1)));
-        HIPCHK_C(hipHostMalloc(&c->h_tie_list, sizeof(uint32_t) * (S + 1), hipHostMallocDefault));
+        c->tie.slots = (uint32_t)(S < (size_t)OPV_TIE_SLOTS_MAX ? S : (size_t)OPV_TIE_SLOTS_MAX);
+        HIPCHK_C(hipHostMalloc((void**)&c->tie.stage, offsetof(OpvTieStage, slot) + sizeof(OpvTieSlot) * c->tie.slots, hipHostMallocDefault));
+        c->tie.stage->n = c->tie.stage->listed = 0;
     }
     HIPCHK_C(hipMemsetAsync(c->d_frames, 0, (size_t)OPV_FB * c->cap_frames * S, c->stream));
     HIPCHK_C(hipMemsetAsync(c->d_counts, 0, sizeof(int32_t) * S, c->stream));
@@ -472,7 +483,7 @@ extern "C" void opv_destroy(opv_ctx* c) {
         if (e) (void)hipEventDestroy(e);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_stall) (void)hipHostFree(c->h_stall);
-    if (c->h_tie_list) (void)hipHostFree(c->h_tie_list);
+    if (c->tie.stage) (void)hipHostFree(c->tie.stage);
     if (c->h_bulk_tab) (void)hipHostFree(c->h_bulk_tab);
     if (c->push_ev) (void)hipEventDestroy(c->push_ev);
     if (c->done_ev) (void)hipEventDestroy(c->done_ev);
@@ -759,42 +770,16 @@ extern "C" int opv_attach_device_iq(opv_ctx* c, int s, const int16_t* d_iq, size
     return OPV_OK;
 }
 
-// Streams whose offset search re-evaluated a candidate (k_offset_search.hip: tie_list): the decision is repeated here with the
-// contenders evaluated by the reference's loop on the host's libm, and the estimate, the energies tap and the tie count of
-// the stream are replaced before the front-end reads them. Waits for the search kernel.
-static int resolve_offset_ties(opv_ctx* c) {
-    const size_t S = (size_t)c->n_streams;
-    const size_t head = S + 1 < 64 ? S + 1 : 64;
-    HIPCHK(hipMemcpyAsync(c->h_tie_list, c->d_tie_list, sizeof(uint32_t) * head, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    size_t n = c->h_tie_list[0];
-    static const bool debug = std::getenv("OPV_TIE_DEBUG") != nullptr;     // (dev switch: how many streams the host decided)
-    if (debug) fprintf(stderr, "opv: offset search: %zu of %zu streams go to the host's libm\n", n, S);
-    if (n == 0) return OPV_OK;
-    if (n > S) return fail(OPV_EHIP, "offset search: tie list overrun (internal)");
-    if (n + 1 > head) HIPCHK(hipMemcpy(c->h_tie_list + head, c->d_tie_list + head, sizeof(uint32_t) * (n + 1 - head), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) {
-        const uint32_t s = c->h_tie_list[1 + i];
-        if (s >= S) return fail(OPV_EHIP, "offset search: bad tie list entry (internal)");
-        OpvStream st;
-        HIPCHK(hipMemcpy(&st, c->d_streams + s, sizeof st, hipMemcpyDeviceToHost));
-        const size_t nsym = st.est_nsym;
-        if (nsym == 0 || nsym > 1000) return fail(OPV_EHIP, "offset search: bad window count (internal)");
-        c->tie_iq.resize(2 * (size_t)OPV_SPS * nsym);
-        HIPCHK(hipMemcpy(c->tie_iq.data(), st.iq, sizeof(int16_t) * c->tie_iq.size(), hipMemcpyDeviceToHost));
-        uint32_t ties = 0;
-        double energies[134];
-        const double est = opv_offset_decide_on_host(c->tie_iq.data(), nsym, st.est_poly, energies, &ties);
-        if (ties == 0) continue;                           // (the same polynomial gives the same contenders: not expected)
-        st.freq_offset = st.est_offset = est;              // demod.set_freq_offset(est) (ref :1033 / :1167)
-        st.est_ties = ties;
-        std::memcpy(st.energies, energies, sizeof energies);
-        char* d = (char*)(c->d_streams + s);
-        HIPCHK(hipMemcpy(d + offsetof(OpvStream, freq_offset), &st.freq_offset, sizeof(double), hipMemcpyHostToDevice));
-        const size_t a = offsetof(OpvStream, est_offset), b = offsetof(OpvStream, energies) + sizeof st.energies;
-        HIPCHK(hipMemcpy(d + a, (const char*)&st + a, b - a, hipMemcpyHostToDevice));
-    }
-    return OPV_OK;
+// The host function of one pass of the tie decision (hipLaunchHostFunc, behind k_tie_collect; k_tie_apply follows): the
+// contenders of every filled slot are evaluated by the reference's loop on the host's libm (opv_offset_host.cpp). Runs on a
+// thread of the runtime in stream order; touches pinned memory and the context's counter only - no HIP call.
+static void tie_host_fn(void* p) {
+    opv_ctx::TieWork* w = (opv_ctx::TieWork*)p;
+    uint32_t n = w->stage->n;
+    if (n > w->slots) n = w->slots;
+    if (n == 0) return;
+    opv_offset_decide_slots(w->stage->slot, n);
+    w->decided.fetch_add(n, std::memory_order_relaxed);
 }
 
 extern "C" int opv_process(opv_ctx* c) {
@@ -805,20 +790,16 @@ extern "C" int opv_process(opv_ctx* c) {
     if (c->round_no >= (unsigned)opv_ctx::kInSlots) HIPCHK(hipEventSynchronize(c->in_ev[slot]));  // upload of round_no-kInSlots done
     StreamIn* in = c->h_in + (size_t)slot * S;
     uint64_t max_new = 0;
-    bool any = false, may_search = false;
+    bool any = false;
+    c->search_now.clear();
     for (int i = 0; i < S; ++i) {
-        HostStream& h = c->hs[i];
+        const HostStream& h = c->hs[i];
         in[i] = {h.d_iq, h.n_avail, h.eof, h.dirty ? 1 : 0, h.popped, h.events_popped};
         if (h.dirty) any = true;
         // k_offset_search's own condition (first full chunk in streaming mode, EOF in batch mode), once per stream
-        if (!h.search_seen && (c->cfg.streaming ? h.n_avail >= (uint64_t)OPV_CHUNK : h.eof != 0)) {
-            h.search_seen = true;
-            may_search |= !(c->cfg.streaming && c->cfg.have_init_offset);
-        }
+        if (!h.search_seen && (c->cfg.streaming ? h.n_avail >= (uint64_t)OPV_CHUNK : h.eof != 0)) c->search_now.push_back(i);
         const uint64_t fresh = h.n_avail - h.last_round_avail;
         if (fresh > max_new) max_new = fresh;
-        h.last_round_avail = h.n_avail;
-        h.dirty = false;
     }
     // nothing new: still run the round while a stream may be waiting behind back-pressure (it resumes by itself once
     // the tracker has consumed soft symbols / the caller has popped frames; the cursors travel with every round).
@@ -831,6 +812,13 @@ extern "C" int opv_process(opv_ctx* c) {
     uint64_t fr = max_new / (uint64_t)(OPV_FSYMS * 38) + 4;
     if (fr > c->cap_frames) fr = c->cap_frames;
     if (fr * (uint64_t)S > 0x7FFFFFFFull) return fail(OPV_EINVAL, "opv_process: streams x frames per round exceeds the grid limit");
+    // the round will be launched: only now is the host's view of the streams advanced (a refused round leaves it untouched)
+    for (int i = 0; i < S; ++i) {
+        HostStream& h = c->hs[i];
+        h.last_round_avail = h.n_avail;
+        h.dirty = false;
+    }
+    for (int i : c->search_now) c->hs[i].search_seen = true;
     c->mirror_valid = false;
     c->maybe_stalled = true;
     c->h_stall[slot] = 0;          // (a straggler of round_no - kInSlots could still set it: then one idle round too many, never one too few)
@@ -844,14 +832,24 @@ extern "C" int opv_process(opv_ctx* c) {
     k_apply_inputs<<<(S + 63) / 64, 64, 0, c->stream>>>(c->d_streams, c->d_in, S);
     const bool tm = c->timing;
     if (tm) HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    const bool host_ties = may_search && c->host_ties;
+    // searches that can run this round (none under a streaming -o: ref :1031), and whether their ties go to the host's libm
+    const size_t n_search = (c->cfg.streaming && c->cfg.have_init_offset) ? 0 : c->search_now.size();
+    const bool host_ties = n_search != 0 && c->host_ties;
     if (host_ties) HIPCHK(hipMemsetAsync(c->d_tie_list, 0, sizeof(uint32_t), c->stream));
     k_offset_search<<<S, 256, 0, c->stream>>>(c->d_streams, g, c->d_offs_wtab, host_ties ? c->d_tie_list : nullptr);
     if (tm) HIPCHK(hipEventRecord(c->ev[1], c->stream));
-    // the one host wait of the path, in the round(s) in which a stream's offset search runs: near-ties are decided with the
-    // host's libm before the front-end takes the estimate (opv_offset_host.cpp)
-    if (host_ties)
-        if (int r = resolve_offset_ties(c)) return r;
+    // near-ties are decided with the host's libm before the front-end takes the estimate, IN STREAM ORDER: per pass of
+    // tie.slots listed streams a kernel stages their inputs in pinned memory, a host function decides them
+    // (opv_offset_host.cpp), a kernel carries the results back. At most n_search streams can be listed, hence the number of
+    // passes; a pass nobody is listed for costs the stream ~25 us (scripts/microbench/hostfunc.hip). The caller never waits.
+    if (host_ties) {
+        const uint32_t K = c->tie.slots, passes = (uint32_t)((n_search + K - 1) / K);
+        for (uint32_t p = 0; p < passes; ++p) {
+            k_tie_collect<<<K, 256, 0, c->stream>>>(c->d_streams, c->d_tie_list, p, K, c->tie.stage);
+            HIPCHK(hipLaunchHostFunc(c->stream, tie_host_fn, &c->tie));
+            k_tie_apply<<<K, 192, 0, c->stream>>>(c->d_streams, c->tie.stage, K, S);
+        }
+    }
     if (tm) HIPCHK(hipEventRecord(c->ev[2], c->stream));
     // one wave per stream has the shortest per-symbol latency (what counts while SIMDs are idle); four streams per
     // wave issue fewer instructions per symbol and stream, which pays once there are more streams than the one-wave
@@ -1129,6 +1127,7 @@ extern "C" int opv_tap_offset_energies(opv_ctx* c, int s, double* out134) {
 }
 
 extern "C" int opv_offset_ties_on_host(opv_ctx* c) { return c && c->host_ties ? 1 : 0; }
+extern "C" uint64_t opv_offset_ties_decided_on_host(opv_ctx* c) { return c ? c->tie.decided.load(std::memory_order_relaxed) : 0; }
 
 extern "C" int opv_tap_wave_info(opv_ctx* c, int s, uint64_t out[4]) {
     if (int r = check_stream(c, s)) return r;

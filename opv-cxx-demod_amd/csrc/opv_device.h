@@ -70,6 +70,7 @@ struct OpvStream {
     uint32_t est_nsym;        // 40-sample windows the search used (min(N, 40 000) / 40, ref :141)
     double energies[134];     // offset-search tap
     double est_poly[2 * OPV_OFFS_TERMS - 1];   // the search's energy polynomial in theta = 2 pi o / Fs (k_offset_search.hip), for the host's tie decision
+    double est_power;         // sum |x|^2 over the samples the search used: scales its two near-tie bands (k_offset_search.hip)
 
     // ---- chunker carry (ref :1012-1076) ----
     uint64_t origin;          // sample index where the next demodulate() call starts
@@ -100,6 +101,30 @@ struct OpvStream {
     // ---- diagnostics of the last front-end launch (opv_tap_wave_info) ----
     uint32_t dbg_hw_id, dbg_xcc_id;   // HW_REG_HW_ID / HW_REG_XCC_ID of the wave that served the stream
     uint64_t dbg_cycles, dbg_ticks;   // s_memtime (shader clock) and s_memrealtime (100 MHz) spent in the kernel
+};
+
+// ---- offset-search ties decided with the host's libm, in stream order (k_offset_search.hip: k_tie_collect / k_tie_apply,
+// opv_offset_host.cpp: opv_offset_decide_slots, opv_capi.hip: opv_process) ----
+// One slot per tied stream and pass, in PINNED host memory: k_tie_collect fills `stream` .. `iq`, a host function enqueued
+// behind it (hipLaunchHostFunc: no HIP call inside) fills `est` .. `energies`, k_tie_apply behind that carries them into the
+// stream's context before the front-end reads the estimate. Nothing waits on the host's side.
+#define OPV_TIE_SLOTS_MAX 256                 // slots per pass (41 MB of pinned memory at most; a context of S streams has min(S, 256))
+struct OpvTieSlot {
+    uint32_t stream;          // index of the stream in its context
+    uint32_t nsym;            // 40-sample windows the search used (<= 1000)
+    double poly[2 * OPV_OFFS_TERMS - 1];   // OpvStream.est_poly
+    double power;             // OpvStream.est_power
+    double est;               // host -> device: the estimate in Hz
+    uint32_t ties;            // host -> device: candidates re-evaluated (0: leave the stream as the device decided it)
+    uint32_t pad;
+    double energies[134];     // host -> device: the search's energies in scan order
+    alignas(16) int16_t iq[2 * OPV_SPS * 1000];   // the first nsym windows of the capture (160 000 B)
+};
+struct OpvTieStage {
+    uint32_t n;               // slots filled in this pass
+    uint32_t listed;          // streams on the tie list in this round (all passes)
+    uint32_t pad[2];
+    OpvTieSlot slot[1];       // [slots]
 };
 
 struct OpvGlobalCfg {

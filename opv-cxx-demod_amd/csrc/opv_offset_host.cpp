@@ -3,17 +3,20 @@
 // k_offset_search.hip evaluates the 134 candidates of MSKDemodulatorAFC::estimate_offset (reference
 // src/opv-demod.cpp:131-202) from ONE pass over the samples; its energies agree with the reference's to ~1e-13
 // relative. When another candidate lies within 1e-11 of the winner the order of the two is decided by the last places
-// of sin / cos - i.e. by libm. The reference's libm is the host's, not the device's: for such a stream opv_process
-// brings the first <= 40 000 samples (160 KB) back and repeats the decision here, the contenders evaluated by the
-// reference's own loop (phases accumulated sample by sample from zero, one sin and one cos per LO and sample, sums in
-// its order) with the host's sin / cos. Same pattern as the transmit chain's ambiguous samples (opv_capi.hip:
-// opv_tx_modulate_device). Compiled with the host compiler, -ffp-contract=off (Makefile: CXXFLAGS).
+// of sin / cos - i.e. by libm. The reference's libm is the host's, not the device's: for such a stream a kernel behind
+// the search copies the first <= 40 000 samples (160 KB) into pinned host memory and a host function enqueued behind THAT
+// (hipLaunchHostFunc; opv_capi.hip: opv_process - the caller does not wait) repeats the decision here, the contenders
+// evaluated by the reference's own loop (phases accumulated sample by sample from zero, one sin and one cos per LO and
+// sample, sums in its order) with the host's sin / cos. Nothing in this file calls HIP. Same idea as the transmit chain's
+// ambiguous samples (opv_capi.hip: opv_tx_modulate_device). Compiled with the host compiler, -ffp-contract=off (Makefile: CXXFLAGS).
 //
 // This is product code: a few candidates of a few streams (the guard fires on <= 4 of 512 ordinary captures), never the
 // whole search and never the receive chain - there is no CPU implementation of the hot path in this library.
+#include <atomic>
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -26,13 +29,18 @@ constexpr double kFs = 2168000.0;                        // ref :40
 constexpr double kFdev = 13550.0;                        // ref :42
 constexpr int kTerms = 2 * OPV_OFFS_TERMS - 1;
 constexpr double kTieRel = 1e-11;                        // k_offset_search.hip: kTieRel
+// k_offset_search.hip: `near` - the same products and the same subtraction, so the same verdicts
+inline bool near(double top, double e, double rel, double power) {
+    const double d = top - e;
+    return d <= rel * top || d * d <= (rel * rel * 40.0) * power * top;
+}
 }  // namespace
 
 // ref :143-159 for one candidate: energy over nsym fixed 40-sample windows from sample 0. The reference's loop is sequential in
 // two cheap things only - the LO phases (one addition per sample, never wrapped, :154-155) and the sum of the window energies
 // (:158); both stay sequential here, in its order. The 160 000 sin / cos in between depend on nothing but a window's starting
 // phases, so the windows are shared out over a few threads: the same numbers, 3 ms -> ~0.4 ms per candidate.
-double opv_offset_candidate_energy(const int16_t* iq, size_t nsym, double offset) {
+double opv_offset_candidate_energy(const int16_t* iq, size_t nsym, double offset, bool threads) {
     const double inc1 = kTwoPi * (-kFdev + offset) / kFs;   // ref :137
     const double inc2 = kTwoPi * (+kFdev + offset) / kFs;   // ref :138
     std::vector<double> start(2 * nsym), energy(nsym);
@@ -63,7 +71,7 @@ double opv_offset_candidate_energy(const int16_t* iq, size_t nsym, double offset
     };
     unsigned nt = std::thread::hardware_concurrency();
     if (nt > 8) nt = 8;
-    if (nt < 2 || nsym < 256) {
+    if (!threads || nt < 2 || nsym < 256) {
         windows(0, nsym);
     } else {
         std::vector<std::thread> pool;
@@ -91,7 +99,8 @@ double opv_offset_candidate_energy(const int16_t* iq, size_t nsym, double offset
 // The decision of k_offset_search.hip (`decide`, coarse then fine), candidate for candidate, with the contenders
 // re-evaluated by opv_offset_candidate_energy. poly: the device's 19 coefficients; the Horner evaluation below is the
 // device's own (fma, same operand order), so the polynomial energies and with them the set of contenders are the device's.
-double opv_offset_decide_on_host(const int16_t* iq, size_t nsym, const double* poly, double* energies134, uint32_t* ties_out) {
+double opv_offset_decide_on_host(const int16_t* iq, size_t nsym, const double* poly, double power, double* energies134, uint32_t* ties_out,
+                                 bool threads) {
     auto poly_energy = [&](double offset) {
         const double th = kTwoPi * offset / kFs;
         double e = poly[kTerms - 1];
@@ -107,15 +116,14 @@ double opv_offset_decide_on_host(const int16_t* iq, size_t nsym, const double* p
         double top = best_e;
         for (int c = c0; c < c1; ++c) top = std::fmax(top, e[c]);
         if (top > 0.0) {
-            const double bar = top * (1.0 - kTieRel);
-            auto in_play = [&](int c) { return e[c] >= bar && !(fine && off(c) == best); };
-            int contenders = (fine && best_e >= bar) ? 1 : 0;
+            auto in_play = [&](int c) { return near(top, e[c], kTieRel, power) && !(fine && off(c) == best); };
+            const bool defend = fine && near(top, best_e, kTieRel, power);   // (decided before any energy is replaced, like the device's uniform flow)
+            int contenders = defend ? 1 : 0;
             for (int c = c0; c < c1; ++c) contenders += in_play(c);
             if (contenders > 1) {
-                const bool defend = fine && best_e >= bar;       // (decided before any energy is replaced, like the device's uniform flow)
                 for (int c = c0; c < c1; ++c)
-                    if (in_play(c)) { e[c] = opv_offset_candidate_energy(iq, nsym, off(c)); ++ties; }
-                if (defend) { best_e = opv_offset_candidate_energy(iq, nsym, best); ++ties; }
+                    if (in_play(c)) { e[c] = opv_offset_candidate_energy(iq, nsym, off(c), threads); ++ties; }
+                if (defend) { best_e = opv_offset_candidate_energy(iq, nsym, best, threads); ++ties; }
             }
         }
         for (int c = c0; c < c1; ++c) {
@@ -135,6 +143,46 @@ double opv_offset_decide_on_host(const int16_t* iq, size_t nsym, const double* p
     return fine_best;
 }
 
+// The slots of one pass (OpvTieStage, pinned host memory; called from the host function opv_process enqueues - no HIP call in
+// here). One tied stream: its candidates' windows are shared out over threads (opv_offset_candidate_energy). Several: the
+// STREAMS are shared out, a candidate evaluated by one thread from start to end - a context whose inputs tie systematically
+// (real-valued captures on every stream) keeps the host's cores busy instead of creating seven threads per candidate.
+// Same numbers either way: windows are independent and their energies are added in the reference's order.
+void opv_offset_decide_slots(OpvTieSlot* slots, uint32_t n) {
+    auto one = [&](OpvTieSlot& sl, bool threads) {
+        sl.ties = 0;
+        if (sl.nsym == 0 || sl.nsym > 1000) return;          // (cannot happen: the device's decision stands)
+        uint32_t ties = 0;
+        double energies[134];
+        const double est = opv_offset_decide_on_host(sl.iq, sl.nsym, sl.poly, sl.power, energies, &ties, threads);
+        if (ties == 0) return;                                // (the same polynomial gives the same contenders: not expected)
+        std::memcpy(sl.energies, energies, sizeof energies);
+        sl.est = est;
+        sl.ties = ties;
+    };
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 8) nt = 8;
+    if (nt > n) nt = n;
+    if (nt < 2) {
+        for (uint32_t i = 0; i < n; ++i) one(slots[i], true);
+        return;
+    }
+    std::atomic<uint32_t> next{0};
+    auto worker = [&] {
+        for (uint32_t i; (i = next.fetch_add(1)) < n;) one(slots[i], false);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nt; ++t) {
+        try {
+            pool.emplace_back(worker);
+        } catch (...) {                                       // no more threads to be had: the ones there are share the slots
+            break;
+        }
+    }
+    worker();
+    for (auto& th : pool) th.join();
+}
+
 // Does THIS process's libm reproduce the energy the reference's evaluation gives (glibc 2.35, x86-64; the pinned value is
 // checked against the test suite's CPU restatement of estimate_offset, itself bit-identical to the compiled reference:
 // tests/test_capi_and_host.py)? 1000 windows of a fixed pseudo-random int16 sequence at +1425 Hz (a coarse candidate, so
@@ -148,7 +196,7 @@ bool opv_offset_host_libm_matches_reference() {
             v = v * 1664525u + 1013904223u;
             iq[k] = (int16_t)((int32_t)(v >> 16) % 4001 - 2000);
         }
-        const double e = opv_offset_candidate_energy(iq, 1000, OPV_OFFSET_PROBE_HZ);
+        const double e = opv_offset_candidate_energy(iq, 1000, OPV_OFFSET_PROBE_HZ, true);
         return e == OPV_OFFSET_PROBE_ENERGY;
     }();
     return ok;

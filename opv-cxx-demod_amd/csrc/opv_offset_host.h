@@ -3,11 +3,16 @@
 #include <stddef.h>
 #include <stdint.h>
 
-// energy of ONE candidate the reference's way (src/opv-demod.cpp:143-159) with the host's libm
-double opv_offset_candidate_energy(const int16_t* iq, size_t nsym, double offset_hz);
-// the whole coarse + fine decision for one stream from the device's polynomial, contenders re-evaluated on the host;
-// fills the 134 energies in scan order and the number of re-evaluations, returns the estimate in Hz
-double opv_offset_decide_on_host(const int16_t* iq, size_t nsym, const double* poly19, double* energies134, uint32_t* ties_out);
+struct OpvTieSlot;   // opv_device.h
+
+// energy of ONE candidate the reference's way (src/opv-demod.cpp:143-159) with the host's libm; threads: share the windows out
+double opv_offset_candidate_energy(const int16_t* iq, size_t nsym, double offset_hz, bool threads);
+// the whole coarse + fine decision for one stream from the device's polynomial and input power, contenders re-evaluated on
+// the host; fills the 134 energies in scan order and the number of re-evaluations, returns the estimate in Hz
+double opv_offset_decide_on_host(const int16_t* iq, size_t nsym, const double* poly19, double power, double* energies134, uint32_t* ties_out,
+                                 bool threads);
+// the same for the n filled slots of one pass of the stream-ordered decision (results left in the slots); no HIP call inside
+void opv_offset_decide_slots(OpvTieSlot* slots, uint32_t n);
 // one-time probe: this process's sin / cos give the pinned energy below for the probe sequence
 bool opv_offset_host_libm_matches_reference();
 

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(amd):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/opv_demod.h but not exported"
     assert sorted(amd.EXPORTS) == names, "opv_amd.EXPORTS out of sync with the header"
-    assert L.opv_abi_version() == 6
+    assert L.opv_abi_version() == 7
 
 
 def test_struct_layouts_match_header(amd, tmp_path):
@@ -351,12 +351,12 @@ def test_offset_tie_host_evaluation_is_the_reference_evaluation(oracle, tmp_path
     L = C.CDLL(str(so))
     energy = getattr(L, name("opv_offset_candidate_energy"))
     energy.restype = C.c_double
-    energy.argtypes = [C.c_void_p, C.c_size_t, C.c_double]
+    energy.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_bool]
     probe = getattr(L, name("opv_offset_host_libm_matches_reference"))
     probe.restype = C.c_bool
     decide = getattr(L, name("opv_offset_decide_on_host"))
     decide.restype = C.c_double
-    decide.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    decide.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_bool]
     assert probe()                                               # this image's glibc gives the pinned energy
     # the probe sequence and its pinned energy (csrc/opv_offset_host.h) against the oracle's table
     v, seq = 0x2545F491, np.empty(80000, np.int16)
@@ -366,7 +366,7 @@ def test_offset_tie_host_evaluation_is_the_reference_evaluation(oracle, tmp_path
     hdr = (pkg / "csrc" / "opv_offset_host.h").read_text()
     pinned = float.fromhex(re.search(r"OPV_OFFSET_PROBE_ENERGY (0x[0-9a-fp.+]+)", hdr).group(1))
     _, e = oracle.estimate_offset(seq, energies=True)
-    assert e[117] == pinned == energy(seq.ctypes.data, 1000, 1425.0)
+    assert e[117] == pinned == energy(seq.ctypes.data, 1000, 1425.0, True) == energy(seq.ctypes.data, 1000, 1425.0, False)
     from oracle_lib import impair
     iq = oracle.modulate(oracle.bert_frames(1))
     noisy = np.ascontiguousarray(impair(iq[: 2 * 30000], amp=1500.0, f0_hz=640.0, ebn0_db=9.0, seed=3))
@@ -375,15 +375,26 @@ def test_offset_tie_host_evaluation_is_the_reference_evaluation(oracle, tmp_path
     for x in (noisy, real):
         off, e = oracle.estimate_offset(x, energies=True)
         nsym = min(x.size // 2, 40000) // 40
-        mine = np.array([energy(x.ctypes.data, nsym, -1500.0 + 25.0 * c) for c in range(121)])
+        mine = np.array([energy(x.ctypes.data, nsym, -1500.0 + 25.0 * c, bool(c & 1)) for c in range(121)])   # (threaded / not: same numbers)
         assert np.array_equal(mine, e[:121])
     assert e[0] == e[120] and off == -1530.0                     # the real-valued capture: an exact mirror tie, first maximum kept
     # the decision: a polynomial in theta whose values at the edge candidates are the winners and equal (even, convex)
     poly = np.zeros(19)
     poly[0], poly[2] = e[60], (e[0] - e[60]) / (2 * np.pi * 1500.0 / 2168000.0) ** 2
     out, ties = np.zeros(134), C.c_uint32(0)
-    est = decide(real.ctypes.data, 1000, poly.ctypes.data, out.ctypes.data, C.byref(ties))
-    assert est == off and ties.value >= 2 and out[0] == e[0] and out[120] == e[120]
+    power = float(np.sum(real.astype(np.float64) ** 2))        # sum |x|^2 over the samples used (exact in fp64)
+    for threads in (True, False):
+        est = decide(real.ctypes.data, 1000, poly.ctypes.data, power, out.ctypes.data, C.byref(ties), threads)
+        assert est == off and ties.value >= 2 and out[0] == e[0] and out[120] == e[120]
+    # the power-scaled band: the same polynomial with its edge values 1e-9 (relative) apart is a clear decision for a signal the
+    # tones match (energy ~ 40 x power: nothing is re-evaluated) and a near-tie for one whose correlation is weak against its
+    # power (energy = 1e-8 x 40 x power: the band is 1e4 times wider)
+    poly2 = poly.copy()
+    poly2[1] = 1e-9 * e[0] / (2 * (2 * np.pi * 1500.0 / 2168000.0))   # odd term: E(+1500) - E(-1500) = 1e-9 E
+    decide(real.ctypes.data, 1000, poly2.ctypes.data, e[0] / 40.0, out.ctypes.data, C.byref(ties), True)
+    assert ties.value == 0
+    decide(real.ctypes.data, 1000, poly2.ctypes.data, e[0] * 1e8 / 40.0, out.ctypes.data, C.byref(ties), True)
+    assert ties.value >= 2
 
 
 def test_rx_bridge_rejects_a_malformed_device_list(amd):

@@ -328,6 +328,64 @@ def test_offset_search_near_ties_on_ordinary_captures(amd, oracle, host, monkeyp
     d.close()
 
 
+def test_process_returns_without_waiting_in_a_search_round(amd, oracle, iq10):
+    """opv_process is asynchronous in EVERY round (include/opv_demod.h, ABI 7). The round in which offset searches run is the
+    one that had a host wait inside until round 5: a tie in the last places of sin / cos is decided with the HOST's libm, and the
+    caller used to wait for the search kernel and the decision. Now kernels stage the tied streams' inputs in pinned memory, a
+    host function enqueued on the context's stream (hipLaunchHostFunc) decides them, and a kernel carries the results back -
+    all behind the search and in front of the front-end, none of it on the caller's thread.
+    2048 streams in one context, three of them constructed ties (real-valued captures: the mirrored candidates tie exactly), every
+    search in the same round: the opv_process CALL returns in under 0.5 ms (the search kernel alone runs longer), the ties are
+    decided by the host (the counter says so) like the reference decides them, and an ordinary stream is untouched."""
+    import time
+    import torch
+    dev = torch.device("cuda", 0)
+    S, n = 2048, 86720
+    t = np.arange(n)
+    ties = []
+    for f_hz, amp, ph in ((33550.0, 9000.0, 0.3), (36000.0, 20000.0, 1.1), (47000.0, 12000.0, 2.0)):
+        x = np.zeros(2 * n, np.int16)
+        x[0::2] = np.rint(amp * np.cos(2 * np.pi * f_hz * t / 2168000.0 + ph))
+        ties.append(x)
+    plain = np.ascontiguousarray(iq10[: 2 * n])
+    d_ties = [torch.from_numpy(x).to(dev) for x in ties]
+    d_plain = torch.from_numpy(plain).to(dev)
+    where = {3: 0, 700: 1, 2047: 2}
+    d = amd.Demod(S, max_samples=n + 64, streaming=True)
+    assert d.offset_ties_on_host()
+    took = []
+    for rnd in range(3):                          # the first round also loads the code objects; the later ones are the measurement
+        if rnd:
+            d.reset(-1)
+        for k in range(S):
+            d.attach(k, (d_ties[where[k]] if k in where else d_plain).data_ptr(), n, eof=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d.process()
+        took.append(time.perf_counter() - t0)
+        d.sync()
+        assert d.offset_ties_decided_on_host() == 3 * (rnd + 1)
+    d.enable_timing(True)
+    d.reset(-1)
+    for k in range(S):
+        d.attach(k, (d_ties[where[k]] if k in where else d_plain).data_ptr(), n, eof=True)
+    d.process()
+    ms = d.kernel_times()
+    print(f"opv_process call in a search round, 2048 streams, 3 host-decided ties: {[f'{1e3 * v:.3f} ms' for v in took]}; "
+          f"on the stream: search {ms['offset_search']:.3f} ms, front-end {ms['msk_frontend']:.3f} ms")
+    assert min(took[1:]) < 0.5e-3, took
+    assert 1e3 * min(took[1:]) < 0.5 * ms["offset_search"], (took, ms)       # the call does not contain the search kernel, let alone the decision
+    for k, i in where.items():
+        off, e = oracle.estimate_offset(ties[i], energies=True)
+        st, g = d.state(k), d.offset_energies(k)
+        assert st.est_offset_hz == off and st.offset_ties >= 2, (k, st.est_offset_hz, off, st.offset_ties)
+        assert int(np.sum(g == e)) >= st.offset_ties - 1, k          # what the host re-evaluated IS the reference's number
+    off, _ = oracle.estimate_offset(plain, energies=True)
+    for k in (0, 4, 699, 701, 2046):
+        assert d.state(k).est_offset_hz == off and d.state(k).offset_ties == 0, k
+    d.close()
+
+
 @pytest.mark.parametrize("tag", ["clean", "p700_16dB_pll20"])
 def test_coherent_prefix_parity(amd, iq10, tag):
     """`-c`: csrc/k_coherent.hip against the reference-made fixtures tests/golden/coherent.*.

@@ -241,26 +241,45 @@ def test_oracle_tx_and_decoder_edges_under_asan(san):
 def test_offset_tie_host_evaluation_under_sanitizers(variant, tmp_path):
     """csrc/opv_offset_host.cpp - the one piece of host ARITHMETIC in the product library (offset-search candidates whose order the
     last places of sin / cos decide, evaluated by the reference's loop on up to eight threads) - under ASan + UBSan and under TSan:
-    a candidate's energy, the whole two-stage decision on an exactly tying (real-valued) capture and the libm probe, with the
-    numbers of the unsanitized build of the same file."""
+    a candidate's energy, the whole two-stage decision on an exactly tying (real-valued) capture, the same decision for five
+    staged streams at once (opv_offset_decide_slots: what the host function of opv_process runs, streams shared out over
+    threads) and the libm probe, with the numbers of the unsanitized build of the same file."""
     src = tmp_path / "m.cpp"
     src.write_text(r'''
 #include <cstdio>
 #include <cstdint>
 #include <cmath>
 #include <vector>
+#include "opv_device.h"
 #include "opv_offset_host.h"
 int main() {
     std::vector<int16_t> iq(2 * 40000, 0);
     for (int n = 0; n < 40000; ++n) iq[2 * n] = (int16_t)std::lrint(9000.0 * std::cos(2 * 3.14159265358979323846 * 36000.0 * n / 2168000.0 + 0.3));
-    const double e0 = opv_offset_candidate_energy(iq.data(), 1000, -1500.0), e1 = opv_offset_candidate_energy(iq.data(), 1000, 1500.0);
-    const double em = opv_offset_candidate_energy(iq.data(), 1000, 0.0);
+    const double e0 = opv_offset_candidate_energy(iq.data(), 1000, -1500.0, true), e1 = opv_offset_candidate_energy(iq.data(), 1000, 1500.0, false);
+    const double em = opv_offset_candidate_energy(iq.data(), 1000, 0.0, true);
+    double power = 0;
+    for (int n = 0; n < 40000; ++n) power += (double)iq[2 * n] * iq[2 * n];
     double poly[19] = {0};
     const double th = 2 * 3.14159265358979323846 * 1500.0 / 2168000.0;
     poly[0] = em; poly[2] = (e0 - em) / (th * th);
     double out[134]; uint32_t ties = 0;
-    const double est = opv_offset_decide_on_host(iq.data(), 1000, poly, out, &ties);
-    std::printf("%a %a %a %.1f %u %d\n", e0, e1, em, est, ties, (int)opv_offset_host_libm_matches_reference());
+    const double est = opv_offset_decide_on_host(iq.data(), 1000, poly, power, out, &ties, true);
+    // five slots: the same capture (the same decision, bit for bit) and one slot nobody can decide (no windows)
+    std::vector<OpvTieSlot> slots(5);
+    for (int k = 0; k < 5; ++k) {
+        OpvTieSlot& sl = slots[k];
+        sl.stream = 7 + k; sl.nsym = k == 3 ? 0 : 1000; sl.power = power; sl.est = 12345.0; sl.ties = 99;
+        for (int i = 0; i < 19; ++i) sl.poly[i] = poly[i];
+        for (int i = 0; i < 80000; ++i) sl.iq[i] = iq[i];
+    }
+    opv_offset_decide_slots(slots.data(), 5);
+    int same = 1;
+    for (int k = 0; k < 5; ++k) {
+        if (k == 3) { same &= slots[k].ties == 0 && slots[k].est == 12345.0; continue; }
+        same &= slots[k].est == est && slots[k].ties == ties && slots[k].stream == 7u + k;
+        for (int c = 0; c < 134; ++c) same &= slots[k].energies[c] == out[c];
+    }
+    std::printf("%a %a %a %.1f %u %d %d\n", e0, e1, em, est, ties, (int)opv_offset_host_libm_matches_reference(), same);
     return 0;
 }
 ''')
@@ -272,5 +291,5 @@ int main() {
                         "-lpthread", "-lm"], check=True)
         outs.append(run([str(exe)]).stdout.decode().split())
     assert outs[0] == outs[1], outs
-    e0, e1, em, est, ties, probe = outs[0]
-    assert e0 == e1 and float.fromhex(e0) > float.fromhex(em) and est == "-1530.0" and int(ties) >= 2 and probe == "1"
+    e0, e1, em, est, ties, probe, same = outs[0]
+    assert e0 == e1 and float.fromhex(e0) > float.fromhex(em) and est == "-1530.0" and int(ties) >= 2 and probe == "1" and same == "1"
