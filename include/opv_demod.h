@@ -133,6 +133,16 @@ typedef struct opv_ctx opv_ctx;
 /* ---- lifetime: replaces constructing MSKDemodulatorAFC + SyncTracker + FrameDecoder
  *      (src/opv-demod.cpp:999-1001 / :1164,:1182-1183) for n_streams independent captures */
 int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg);
+/* Environment variables. The library reads FOUR, all of them TEST HOOKS - never set in production -, all of them in opv_create
+ * and nowhere else (a context's behaviour is fixed when it is created; grep getenv csrc/):
+ *   OPV_OFFSET_DISTRUST_LIBM  (any value) the offset search's last-place ties are decided by the device's sincos although the host's
+ *                             libm reproduces the reference's (opv_offset_ties_on_host() == 0): moves a stream whose search ties
+ *                             from the class "decided like the reference" to "decided by another libm". The fallback's tests use it.
+ *   OPV_TX_DISTRUST_LIBM      (any value) the device transmit chain takes every symbol's flat-top bits from the host's libm instead of
+ *                             the zone rule its one-time probe of sin / cos allows: same samples, slower set-up. The fallback's test uses it.
+ *   OPV_PUSH_NO_GATHER        (any value) opv_push_iq_batch(_async) moves pinned blocks with one copy per block instead of one gather
+ *                             kernel: same bytes, the path pageable sources take anyway. Its test runs both.
+ *   OPV_PUSH_GATHER_BLOCKS    (a number > 0) workgroups of that gather kernel (default 32; a measurement knob, results unaffected). */
 void opv_destroy(opv_ctx* ctx);
 const char* opv_last_error(void);
 int opv_abi_version(void);
@@ -254,7 +264,7 @@ int opv_tap_offset_energies(opv_ctx* ctx, int stream, double* out134);
  * the reference's order of operations, are within 2e-13 of each other - what the last places of sin / cos can move - or equal,
  * src/opv-demod.cpp:161,195): 1 = the host, with the contenders evaluated by the reference's own loop on the
  * host's libm - opv_create found that this process's sin / cos reproduce a pinned reference energy (csrc/opv_offset_host.cpp);
- * 0 = the device's sincos (another libm on the host, or OPV_OFFSET_DISTRUST_LIBM set): still the reference's order of
+ * 0 = the device's sincos (another libm on the host, or the test hook OPV_OFFSET_DISTRUST_LIBM, see opv_create): still the reference's order of
  * operations, counted in offset_ties, but an exact tie is then decided by a different libm than the reference's. */
 int opv_offset_ties_on_host(opv_ctx* ctx);
 /* Streams whose tie the host has decided so far in this context (they are decided in stream order behind their search kernel,

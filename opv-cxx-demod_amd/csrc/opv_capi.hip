@@ -227,6 +227,9 @@ struct opv_ctx {
     // tie_slots streams, k_tie_collect -> a host function -> k_tie_apply (TieWork below), and the front-end behind those
     uint32_t* d_tie_list = nullptr;
     bool host_ties = false;             // the host's libm reproduces the pinned reference energy (probed at opv_create)
+    bool tx_trust_libm = false;         // the host's sin / cos behave at the transmit NCOs' flat tops as k_tx_modulate.hip assumes (probed at opv_create)
+    bool push_gather = true;            // opv_push_iq_batch moves pinned blocks with one gather kernel (else: one copy per block)
+    uint32_t push_gather_blocks = 32;   // workgroups of that kernel (see push_deferred)
     struct TieWork {                    // what the host function gets: stable for the context's life (opv_destroy drains the stream first)
         OpvTieStage* stage = nullptr;   // pinned: header + tie_slots slots
         uint32_t slots = 0;
@@ -331,7 +334,6 @@ struct opv_ctx {
 constexpr double kFlatExact = 0.90e-8, kFlatBelow = 1.25e-8;
 static bool libm_flat_tops_as_assumed() {
     static const bool ok = [] {
-        if (std::getenv("OPV_TX_DISTRUST_LIBM")) return false;             // (test hook: forces the every-symbol-from-libm path)
         const double pi = 3.14159265358979323846;
         const struct { bool is_sin; double x0; } tops[] = {{true, pi / 2}, {true, -pi / 2}, {false, 0.0}, {false, pi}, {false, -pi}};
         for (const auto& t : tops)
@@ -432,7 +434,12 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
         HIPCHK_C(hipMalloc(&c->d_offs_wtab, sizeof(double) * w.size()));
         HIPCHK_C(hipMemcpy(c->d_offs_wtab, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice));
     }
-    c->host_ties = opv_offset_host_libm_matches_reference() && !std::getenv("OPV_OFFSET_DISTRUST_LIBM");   // (test hook: the device-sincos path)
+    // The library's four environment switches, all TEST HOOKS (include/opv_demod.h has the table): read here, once per context,
+    // and nowhere else - a context never changes its behaviour after it has been created.
+    c->host_ties = opv_offset_host_libm_matches_reference() && !std::getenv("OPV_OFFSET_DISTRUST_LIBM");
+    c->tx_trust_libm = libm_flat_tops_as_assumed() && !std::getenv("OPV_TX_DISTRUST_LIBM");
+    c->push_gather = !std::getenv("OPV_PUSH_NO_GATHER");
+    if (const char* e = std::getenv("OPV_PUSH_GATHER_BLOCKS")) { const int v = atoi(e); if (v > 0) c->push_gather_blocks = (uint32_t)v; }
     if (c->host_ties) {
         HIPCHK_C(hipMalloc(&c->d_tie_list, sizeof(uint32_t) * (S + 1)));
         c->tie.slots = (uint32_t)(S < (size_t)OPV_TIE_SLOTS_MAX ? S : (size_t)OPV_TIE_SLOTS_MAX);
@@ -642,7 +649,7 @@ static int push_deferred(opv_ctx* c, const std::vector<DeferredCopy>& copies) {
     CompactItem* items = nullptr;
     PushPair* pairs = nullptr;
     uint32_t m = 0, most = 0;
-    const bool try_gather = copies.size() >= 2 && !std::getenv("OPV_PUSH_NO_GATHER");   // (test hook: the per-stream copies)
+    const bool try_gather = copies.size() >= 2 && c->push_gather;
     if (try_gather)
         if (int r = bulk_table(c, copies.size() > (size_t)c->n_streams ? copies.size() : (size_t)c->n_streams, &items, &pairs)) return r;
     for (const DeferredCopy& k : copies) {
@@ -673,8 +680,7 @@ static int push_deferred(opv_ctx* c, const std::vector<DeferredCopy>& copies) {
         const uint32_t by_size = most / (256u * 16u);                 // ... but never thinner than one 16-byte move per lane of a block
         if (slices > by_size) slices = by_size ? by_size : 1;
         uint32_t grid = m * slices;
-        static const uint32_t max_grid = [] { const char* e = std::getenv("OPV_PUSH_GATHER_BLOCKS"); const int v = e ? atoi(e) : 0; return (uint32_t)(v > 0 ? v : 32); }();   // (dev switch)
-        if (grid > max_grid) grid = max_grid;
+        if (grid > c->push_gather_blocks) grid = c->push_gather_blocks;
         k_push_gather<<<grid, 256, 0, c->copy_stream>>>((const PushPair*)d_pairs, m, slices);
         HIPCHK(hipGetLastError());
     }
@@ -1277,7 +1283,7 @@ extern "C" long opv_tx_modulate_device(opv_ctx* c, const uint8_t* frames, size_t
             return lo;
         };
         const size_t j_lo = n_ck ? first_at(kFlatExact) : 0, j_hi = n_ck ? first_at(kFlatBelow) : 0;
-        bool ok = libm_flat_tops_as_assumed();
+        bool ok = c->tx_trust_libm;
         for (size_t t = 0; ok && n_ck && t < 16; ++t) {     // the partition the search assumed, at 16 places across the run
             const size_t j = t * (n_ck - 1) / 15;
             const double d = drift(j);

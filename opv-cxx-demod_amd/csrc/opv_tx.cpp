@@ -171,9 +171,6 @@ void opv_tx_symbol_phases(size_t first_symbol, size_t n_symbols, double* ph1_io,
 void opv_tx_checkpoint_range(size_t first, size_t count, double* out2) {
     size_t n_tab = 0;
     const double* tab = opv_tx_checkpoints(&n_tab);
-    // dev switch (read once): pretend the table is shorter, so that tests reach the host continuation at small sizes
-    static const size_t limit = [] { const char* e = std::getenv("OPV_TX_CKPT_LIMIT"); return e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)-1; }();
-    if (limit >= 1 && limit < n_tab) n_tab = limit;
     size_t k = 0;
     for (; k < count && first + k < n_tab; ++k) { out2[2 * k] = tab[2 * (first + k)]; out2[2 * k + 1] = tab[2 * (first + k) + 1]; }
     if (k == count) return;

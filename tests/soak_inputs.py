@@ -111,6 +111,42 @@ def symmetric_openings(seed, n_streams=208):
     return caps
 
 
+def weak_correlation_openings(seed, n_streams=96):
+    """n_streams captures whose correlation with the tone pair is WEAK against their power - the inputs on which the errors of an
+    offset-search energy are large relative to the energy itself (they scale with sqrt(energy x power), k_offset_search.hip): a
+    complex tone far outside the pair with noise, a strong interferer over a faint MSK signal, a few LSB of noise on a DC offset,
+    and - the ones that put two candidates within rounding of each other without an exact mirror - a real tone whose other
+    branch carries one LSB of noise. Lengths around the 40 000 samples the search uses."""
+    from oracle_lib import Oracle, impair
+    o = Oracle()
+    rng = np.random.default_rng(seed)
+    base = o.modulate(o.bert_frames(2, "W%d" % (seed % 1000), first=seed))
+    caps = []
+    for k in range(n_streams):
+        n = int(rng.choice([12000, 39999, 40000, 40040, 44000]))
+        t = np.arange(n)
+        kind = k % 4
+        amp = float(rng.uniform(500, 15000))
+        if kind == 0:                                            # complex tone on a null of one tone's 40-sample window (a sidelobe of the other's) + complex noise
+            f = float(rng.choice([-1, 1]) * (13550.0 + 54200.0 * int(rng.integers(1, 18)) + rng.uniform(-800, 800)))
+            v = amp * np.exp(2j * np.pi * f * t / 2168000.0 + 1j * rng.uniform(0, 6.28)) \
+                + 10.0 ** rng.uniform(-3, -1) * amp * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        elif kind == 1:                                          # strong interferer over a faint MSK signal
+            at = int(rng.integers(0, base.size // 2 - n - 1))
+            x = impair(base[2 * at: 2 * (at + n)], amp=float(rng.uniform(20, 300)), f0_hz=float(rng.uniform(-1400, 1400)), ebn0_db=None, seed=seed * 1000 + k)
+            v = x[0::2] + 1j * x[1::2] + amp * np.exp(2j * np.pi * float(rng.uniform(40000, 300000)) * t / 2168000.0)
+        elif kind == 2:                                          # a few LSB of noise on a DC offset
+            v = amp * np.exp(1j * rng.uniform(0, 6.28)) + rng.uniform(0.5, 3.0) * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        else:                                                    # a real tone, one LSB of noise on the other branch: near, not exact, mirror ties
+            f = float(rng.uniform(30000, 60000))
+            v = amp * np.cos(2 * np.pi * f * t / 2168000.0 + rng.uniform(0, 6.28)) + 1j * rng.uniform(0.3, 1.0) * rng.standard_normal(n)
+        x = np.zeros(2 * n, np.int16)
+        x[0::2] = np.clip(np.rint(v.real), -32768, 32767)
+        x[1::2] = np.clip(np.rint(v.imag), -32768, 32767)
+        caps.append(x)
+    return caps
+
+
 def offset_opening(seed, k):
     """ONE opening for estimate_offset, a function of (seed, k) alone (so that single finds of scripts/experiments/near_tie_hunt.py
     can be regenerated): a random start inside a 3-frame BERT run, carrier offset within and beyond the search span, level,
