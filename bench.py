@@ -20,10 +20,13 @@ encode -> channel -> decode round trip). `value` is units / the bracketed time o
 the median step ("median of >= 5") is reported next to it, and extras.all_clean_variant is C4's
 "all-clean variant": the same 64 x 1000 captures straight from the modulator.
 
-Also reported (same run, outside the timed steps): configs[1] (ONE clean 1000-frame stream)
-and a many-short-streams sweep that shows the throughput-bound regime; the reference
-`opv-demod -s -r -q` itself timed on the host (cpu_baseline.kind = "reference") when the
-prebuilt oracle/_ref binary travelled with the snapshot, else the C oracle ("port").
+Also reported (same run, outside the timed steps): the reference `opv-demod -s -r -q` itself timed on the host
+(cpu_baseline.kind = "reference") when the prebuilt oracle/_ref binary travelled with the snapshot, else the C oracle
+("port") - always - and the EXTRAS: configs[1] (ONE clean 1000-frame stream), the all-clean variant, a many-short-streams
+sweep that shows the throughput-bound regime, configs[4]'s whole workload on one GPU, 32 768 unique streams, the
+PCIe-inclusive rates, the live-serving capacity. The extras share ONE wall-clock budget (--extras-budget, default 70 s): they
+run in a fixed order of priority, each only if its estimated cost still fits, and extras.skipped_for_budget names the ones
+that did not (profiles/collect.sh records the line with a budget that holds them all).
 """
 import argparse
 import ctypes
@@ -124,28 +127,65 @@ def cli_drop_in(iq_bytes, n_samples):
             "what": "bin/opv-demod -s -r -q (one stream = one wavefront) on the capture the reference binary was timed on, via a pipe"}
 
 
-def live_capacity(dev_index):
+class Budget:
+    """One wall-clock budget for everything bench.py does beyond the contract's line: an extra runs only if its estimated cost
+    still fits; what was skipped and what each one took is part of the line (extras.budget, extras.skipped_for_budget)."""
+
+    def __init__(self, seconds):
+        self.seconds = float(seconds)
+        self.t_end = time.perf_counter() + self.seconds
+        self.skipped, self.spent = [], {}
+
+    def left(self):
+        return self.t_end - time.perf_counter()
+
+    def run(self, name, est_s, fn, always=False):
+        """fn() if `est_s` still fits (or `always`: the contract's cpu_baseline is not optional, only accounted for);
+        an extra that raises costs its own entry, never the bench line"""
+        if not always and self.left() < est_s:
+            self.skipped.append({"extra": name, "needs_s": est_s, "left_s": round(max(self.left(), 0.0), 1)})
+            return None
+        t0 = time.perf_counter()
+        try:
+            return fn()
+        except AssertionError:
+            raise
+        except Exception as e:
+            return {"error": repr(e)[:300]}
+        finally:
+            self.spent[name] = round(time.perf_counter() - t0, 1)
+
+    def report(self):
+        return {"seconds": self.seconds, "spent_s": self.spent, "spent_total_s": round(sum(self.spent.values()), 1),
+                "order": "cpu_baseline (always), configs[1], all-clean variant, cpu on all cores, stream sweep, configs[4] on one GPU, "
+                         "many unique streams, PCIe-inclusive + live round, CLI drop-in, live capacity"}
+
+
+def live_capacity(dev_index, budget=None):
     """The reference's real caller shape (`opv-modem -R`, src/opv-modem.cpp:673-838: IQ arrives at 2.168 MSPS, 40 ms per frame), for N
     streams at once: how many live streams ONE context serves in real time. bin/opv-live-capacity (host/opv_live_capacity.cpp, a
     C++ caller of the C ABI like opv-rx-bridge) runs 120 serving rounds - one 86 720-sample chunk per stream pushed from pinned host
     memory over PCIe (every stream's chunk at its own host addresses: N x 347 KB of distinct memory per round), opv_process, every
     stream's frames popped and compared with what was sent - and reports the round-time distribution; the capacity is the largest N
-    probed whose p99 round stays under the 40 ms of signal a round consumes. Doubling, then bisection to 256 streams - for the serial
-    loop (push, process, pop) and, upwards from there, for the double-buffered one (opv_push_iq_batch_async: round r + 1 crosses PCIe
-    while round r is processed and popped)."""
+    probed whose p99 round stays under the 40 ms of signal a round consumes. Bisection of [1024, 8192] to 512 streams for the serial
+    loop (push, process, pop), then of [that, that + 2048] for the double-buffered one (opv_push_iq_batch_async: round r + 1
+    crosses PCIe while round r is processed and popped): about eight probes of ~9 s where the doubling + linear walk of round 5 took
+    fifteen. Every probe is charged to the extras' budget; when that runs out the search ends with the best bracket it has
+    ("cut_short")."""
     exe = ROOT / "opv-cxx-demod_amd" / "bin" / "opv-live-capacity"
     if not exe.exists():
         return None
     probes = {}
-    t_end = time.perf_counter() + 150.0                # the whole search is bounded: the bench line must not wait minutes for an extra
+    t_end = time.perf_counter() + (budget.left() if budget is not None else 150.0)   # the whole search is bounded by the extras' budget
+    cut = []
 
     def probe(n, pipelined=False):
         key = (n, pipelined)
         if key not in probes:
             left = t_end - time.perf_counter()
-            if left < 10.0:
-                probes[key] = {"streams": n, "pipelined": pipelined, "error": "search time used up (150 s)", "rc": None}
-                return False
+            if left < 12.0:                            # a probe: process start + 120 rounds of <= 40 ms + the check
+                cut.append(n)
+                return None
             try:
                 p = subprocess.run([str(exe), str(n), "120", "6", str(dev_index)] + (["--pipelined"] if pipelined else []),
                                    capture_output=True, text=True, timeout=min(60.0, left))
@@ -155,32 +195,39 @@ def live_capacity(dev_index):
                 probes[key] = {"streams": n, "pipelined": pipelined, "error": "probe timed out", "rc": None}
         r = probes[key]
         return "error" not in r and r["round_ms_p99"] < 40.0 and r["frames_wrong"] == 0
-    lo, hi = 0, None
-    n = 1024
-    while n <= 16384:
-        if probe(n):
-            lo = n
-            n *= 2
-        else:
-            hi = n
-            break
-    while hi is not None and hi - lo > 256:
-        mid = (lo + hi) // 2 // 256 * 256
-        if mid <= lo or mid >= hi:
-            break
-        if probe(mid):
-            lo = mid
-        else:
-            hi = mid
-    plo = 0
-    if lo:
-        n = lo
-        while n <= 16384 and n - lo <= 2048 and probe(n, True):     # upwards from the serial figure, 256 streams at a time
-            plo = n
-            n += 256
+
+    def bisect(lo, hi, pipelined, step=512):
+        """largest n in [lo, hi) on the grid of `step` that passes, given that lo is known (or assumed) to pass and hi to fail"""
+        while hi - lo > step:
+            mid = (lo + hi) // 2 // step * step
+            if mid <= lo or mid >= hi:
+                break
+            ok = probe(mid, pipelined)
+            if ok is None:
+                break
+            if ok:
+                lo = mid
+            else:
+                hi = mid
+        return lo, hi
+    lo, hi = 0, 8192
+    first = probe(1024)
+    if first:
+        lo, hi = bisect(1024, 8192, False)
+    plo, phi = 0, None
+    if lo and not cut:
+        plo, phi = lo, lo + 2048
+        ok = probe(phi, True)                          # does the double-buffered loop carry 2048 streams more?
+        if ok:
+            plo, phi = phi, None
+        elif ok is not None:
+            plo, phi = bisect(lo, phi, True)
+            if plo == lo and not probe(lo, True):      # (the bracket's lower end was an assumption)
+                plo = 0
     best, pbest = probes.get((lo, False)), probes.get((plo, True))
     return {"streams": lo, "round_ms_p99": best["round_ms_p99"] if best else None, "round_ms_p50": best["round_ms_p50"] if best else None,
             "Msamples/s_sustained": round(lo * 2.168, 1), "first_n_over_40ms": hi,
+            "cut_short": {"probes_not_run": cut, "why": "the extras' wall-clock budget ran out; the figures are the best bracket reached"} if cut else None,
             "pipelined": {"streams": plo, "round_ms_p99": pbest["round_ms_p99"] if pbest else None, "round_ms_p50": pbest["round_ms_p50"] if pbest else None,
                           "Msamples/s_sustained": round(plo * 2.168, 1),
                           "what": "the same rounds with opv_push_iq_batch_async: the next round's chunks cross PCIe while this round is processed and popped"},
@@ -232,6 +279,9 @@ def main():
     ap.add_argument("--ebn0", type=float, default=16.0, help="dB; <=0 disables noise")
     ap.add_argument("--no-extras", action="store_true", help="skip configs[1], the sweep and the CPU baseline")
     ap.add_argument("--no-big", action="store_true", help="skip the 512-stream x F-frame single-GPU run of the extras (178 GB of HBM)")
+    ap.add_argument("--extras-budget", type=float, default=70.0,
+                    help="wall-clock seconds for everything beyond the contract's line (the extras, in a fixed order of priority; "
+                         "what does not fit is listed in extras.skipped_for_budget)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -473,6 +523,14 @@ def main():
     else:
         regime = f"{waves} waves on {n_simd} SIMDs: every SIMD carries a stream wave, the kernel is at the chip's issue capacity"
 
+    # the bound that binds FIRST in the note: a record that keeps only the note's head still says why 0.4 % of HBM is not the story
+    if binding["frac"] is not None and binding["bound"] == "wave-issue":
+        binding_head = f"binding=wave-issue {binding['frac']:.3f} ({binding['achieved'] / 4.0:.0f} instr x 4 / {binding['peak']:.1f} cyc); "
+    elif binding["frac"] is not None:
+        binding_head = f"binding=chip-issue {binding['frac']:.3f} (issued wave-instructions / (1024 SIMDs x kernel cycles / 4)); "
+    else:
+        binding_head = f"binding={binding['bound']} n/a (no SQ_INSTS pass stored for this kernel / workload); "
+
     out = {
         "metric": "IQ Msamples/s demod+Viterbi (×real-time @2.168MSPS); BER vs ref",
         "value": round(msps, 3), "unit": "Msamples/s", "x_realtime": round(msps / 2.168, 1),
@@ -499,7 +557,7 @@ def main():
                      "issue": issue,
                      "fp64_valu": fp64_view,
                      "kernel_ms": round(fe_ms, 3),
-                     "note": regime + "; extras.stream_sweep shows the front-end with the chip filled"},
+                     "note": binding_head + regime + "; extras.stream_sweep shows the front-end with the chip filled"},
         "kernel_ms": {k: round(float(np.mean([x[k] for x in kt])), 3) for k in kt[0]},
         "check": stats,
     }
@@ -511,264 +569,288 @@ def main():
 
     if rank == 0 and not args.no_extras and world == 1:
         extras = {}
-        # configs[1]: one clean 1000-frame stream
+        budget = Budget(args.extras_budget)
+
+        def put(key, est_s, fn):
+            r = budget.run(key, est_s, fn)
+            if r is not None:
+                extras[key] = r
+        # the clean 1000-frame capture of configs[1] (W5NYV), made on the device: the CPU baseline's input as well
         one = amd.Demod(1, max_samples=n + 64, streaming=True, device=dev_index)
         d_base = torch.empty(2 * n, dtype=torch.int16, device=dev)
         t0 = time.perf_counter()
         one.modulate_device(tx_frames, d_base.data_ptr())
         one.sync()
         t_dev_mod = time.perf_counter() - t0
-        for rep in range(2):
-            one.reset()
-            one.attach(0, d_base.data_ptr(), n, eof=True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            one.process()
-            one.sync()
-            t1 = time.perf_counter() - t0
-        fr, meta = one.pop_frames(0)
-        assert np.array_equal(fr, tx_frames), "configs[1] frames differ"
-        extras["configs1_single_clean_stream"] = {"Msamples/s": round(n / t1 / 1e6, 3), "ms": round(t1 * 1e3, 2),
-                                                   "frames": int(len(fr)), "all_metric_0": bool((meta["viterbi_metric"] == 0).all())}
-        one.close()
-        # SURVEY.md §8d C4's "all-clean variant for peak throughput": the same S per-stream BERT captures exactly as the
-        # modulator emits them (full scale, no offset, no noise), same context, same step (reset, S attaches, opv_process,
-        # sync); every frame must equal the transmitted one with Viterbi metric 0
-        try:
-            d_cl, tx_cl, _n = workload.generate(amd, dm, torch, dev, mine, F, None, clean=True)
-            cl_s, cl_fe = [], []
-            for rep in range(1 + max(5, args.steps)):
-                dm.reset()
-                for k in range(S):
-                    dm.attach(k, d_cl[k].data_ptr(), n, eof=True)
+        raw = d_base.cpu().numpy().tobytes()
+        # the contract's cpu_baseline: not optional, only accounted for
+        t0 = time.perf_counter()
+        out["cpu_baseline"] = cpu_baseline(raw, n)
+        budget.spent["cpu_baseline"] = round(time.perf_counter() - t0, 1)
+
+        def x_configs1():                                # configs[1]: one clean 1000-frame stream
+            for rep in range(2):
+                one.reset()
+                one.attach(0, d_base.data_ptr(), n, eof=True)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                dm.process()
-                dm.sync()
-                if rep:                                  # (the first one is the warm-up run)
-                    cl_s.append(time.perf_counter() - t0)
-                    cl_fe.append(dm.kernel_times()["msk_frontend"])
-            exp_c = torch.from_numpy(tx_cl).to(dev)
-            cl_bad = int((frames_view[:, :F, :] != exp_c).any(dim=2).sum().item())
-            cl_cnt = bool((counts_view == F).all().item())
-            cl_states = [dm.state(k) for k in range(S)]
-            cl_med = float(np.median(cl_s))
-            extras["all_clean_variant"] = {
-                "workload": f"{S} streams x {F} frames straight from the device modulator (amplitude 16383, no offset, no noise)",
-                "Msamples/s": round(S * n / cl_med / 1e6, 3), "x_realtime": round(S * n / cl_med / 2.168e6, 1),
-                "ms_per_step_median": round(cl_med * 1e3, 3), "steps": len(cl_s), "frontend_ms_median": round(float(np.median(cl_fe)), 3),
-                "every_stream_released_all_frames": cl_cnt, "frames_exact": S * F - cl_bad, "frames_total": S * F,
-                "frames_perfect": int(sum(st.frames_perfect for st in cl_states)),
-                "edge_ties": int(sum(st.edge_ties for st in cl_states)), "offset_ties": int(sum(st.offset_ties for st in cl_states))}
-            assert cl_cnt and cl_bad == 0, "all-clean variant: a decoded frame differs from the transmitted one"
-            del d_cl, exp_c
-            torch.cuda.empty_cache()
-        except AssertionError:
-            raise
-        except Exception as e:                           # an extra must never cost the bench line
-            extras["all_clean_variant"] = {"error": repr(e)[:300]}
-        step(check=False)                                # dm's frame buffer holds the contract workload's frames again (compared below)
-        # throughput-bound regime: many short streams carved out of the resident captures
-        sweep = {}
-        for ns, nfr in ((128, 480), (192, 320), (256, 240), (512, 120), (1024, 60), (2048, 30), (4096, 15), (8192, 7), (16384, 3)):
-            if nfr > F:
-                continue
-            per = F // nfr
-            if S * per < ns:
-                continue
-            sub_n = nfr * FRAME_SAMPLES
-            m = amd.Demod(ns, max_samples=sub_n + 64, streaming=True, device=dev_index)
-            m.enable_timing(True)
-            ent = {}
-            for spw in (1, 4, 16):                      # streams per wavefront (opv_set_frontend)
-                if spw == 4 and ns < 4096:         # (the four-per-wave mapping is the automatic choice from 2049 streams on)
-                    continue
-                if spw == 16 and ns < 4096:        # (sixteen per wave: 1024 waves = one per SIMD need 16 384 streams)
-                    continue
-                if spw == 1 and ns > 8192:
-                    continue
-                m.set_frontend(spw)
-                for rep in range(2):
-                    m.reset()
-                    for j in range(ns):
-                        k, seg = j % S, j // S
-                        m.attach(j, d_iq[k].data_ptr() + 4 * seg * sub_n, sub_n, eof=True)
+                one.process()
+                one.sync()
+                t1 = time.perf_counter() - t0
+            fr, meta = one.pop_frames(0)
+            assert np.array_equal(fr, tx_frames), "configs[1] frames differ"
+            return {"Msamples/s": round(n / t1 / 1e6, 3), "ms": round(t1 * 1e3, 2),
+                    "frames": int(len(fr)), "all_metric_0": bool((meta["viterbi_metric"] == 0).all())}
+        put("configs1_single_clean_stream", 4.0, x_configs1)
+        one.close()
+
+        def x_all_clean():
+            # SURVEY.md §8d C4's "all-clean variant for peak throughput": the same S per-stream BERT captures exactly as the
+            # modulator emits them (full scale, no offset, no noise), same context, same step (reset, S attaches, opv_process,
+            # sync); every frame must equal the transmitted one with Viterbi metric 0
+            try:
+                d_cl, tx_cl, _n = workload.generate(amd, dm, torch, dev, mine, F, None, clean=True)
+                cl_s, cl_fe = [], []
+                for rep in range(1 + max(5, args.steps)):
+                    dm.reset()
+                    for k in range(S):
+                        dm.attach(k, d_cl[k].data_ptr(), n, eof=True)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    m.process()
-                    m.sync()
+                    dm.process()
+                    dm.sync()
+                    if rep:                                  # (the first one is the warm-up run)
+                        cl_s.append(time.perf_counter() - t0)
+                        cl_fe.append(dm.kernel_times()["msk_frontend"])
+                exp_c = torch.from_numpy(tx_cl).to(dev)
+                cl_bad = int((frames_view[:, :F, :] != exp_c).any(dim=2).sum().item())
+                cl_cnt = bool((counts_view == F).all().item())
+                cl_states = [dm.state(k) for k in range(S)]
+                cl_med = float(np.median(cl_s))
+                res_clean = {
+                    "workload": f"{S} streams x {F} frames straight from the device modulator (amplitude 16383, no offset, no noise)",
+                    "Msamples/s": round(S * n / cl_med / 1e6, 3), "x_realtime": round(S * n / cl_med / 2.168e6, 1),
+                    "ms_per_step_median": round(cl_med * 1e3, 3), "steps": len(cl_s), "frontend_ms_median": round(float(np.median(cl_fe)), 3),
+                    "every_stream_released_all_frames": cl_cnt, "frames_exact": S * F - cl_bad, "frames_total": S * F,
+                    "frames_perfect": int(sum(st.frames_perfect for st in cl_states)),
+                    "edge_ties": int(sum(st.edge_ties for st in cl_states)), "offset_ties": int(sum(st.offset_ties for st in cl_states))}
+            finally:
+                d_cl = exp_c = None
+                torch.cuda.empty_cache()
+                step(check=False)                        # dm's frame buffer holds the contract workload's frames again (compared below)
+            assert cl_cnt and cl_bad == 0, "all-clean variant: a decoded frame differs from the transmitted one"
+            return res_clean
+        put("all_clean_variant", 14.0, x_all_clean)
+        put("cpu_baseline_all_cores", 5.0, lambda: cpu_all_cores(raw, n))
+
+        def x_sweep():                                   # throughput-bound regime: many short streams carved out of the resident captures
+            sweep = {}
+            for ns, nfr in ((128, 480), (192, 320), (256, 240), (512, 120), (1024, 60), (2048, 30), (4096, 15), (8192, 7), (16384, 3)):
+                if nfr > F:
+                    continue
+                per = F // nfr
+                if S * per < ns:
+                    continue
+                sub_n = nfr * FRAME_SAMPLES
+                m = amd.Demod(ns, max_samples=sub_n + 64, streaming=True, device=dev_index)
+                m.enable_timing(True)
+                ent = {}
+                for spw in (1, 4, 16):                      # streams per wavefront (opv_set_frontend)
+                    if spw == 4 and ns < 4096:         # (the four-per-wave mapping is the automatic choice from 2049 streams on)
+                        continue
+                    if spw == 16 and ns < 4096:        # (sixteen per wave: 1024 waves = one per SIMD need 16 384 streams)
+                        continue
+                    if spw == 1 and ns > 8192:
+                        continue
+                    m.set_frontend(spw)
+                    for rep in range(2):
+                        m.reset()
+                        for j in range(ns):
+                            k, seg = j % S, j // S
+                            m.attach(j, d_iq[k].data_ptr() + 4 * seg * sub_n, sub_n, eof=True)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        m.process()
+                        m.sync()
+                        t1 = time.perf_counter() - t0
+                    f_, m_, c_, cap_ = m.device_frames()
+                    cnt = torch.as_tensor(DevPtr(c_, (ns,), "<i4"), device=dev).cpu().numpy()
+                    fe_ms = m.kernel_times()["msk_frontend"]
+                    ent[f"{spw}_per_wave"] = {"Msamples/s": round(ns * sub_n / t1 / 1e6, 1), "ms": round(t1 * 1e3, 2),
+                                              "frontend_alone_Msamples/s": round(ns * sub_n / fe_ms / 1e3, 1),
+                                              "frames_released": int(cnt.sum())}
+                sweep[f"{ns}x{nfr}"] = ent
+                m.close()
+            return sweep
+        put("stream_sweep", 24.0, x_sweep)
+        if "stream_sweep" in extras and "error" not in extras["stream_sweep"]:
+            sweep = extras["stream_sweep"]
+            tgt = [int(k.split("x")[0]) for k, v in sweep.items() if max(e["Msamples/s"] for e in v.values()) >= 21680.0]
+            extras["streams_for_target"] = {"target_Msamples/s": 21680.0, "smallest_swept_stream_count_meeting_it": min(tgt) if tgt else None,
+                                            "swept": sorted(int(k.split("x")[0]) for k in sweep)}
+
+        def x_configs4():
+            # BASELINE configs[4]'s whole workload (512 streams x F frames, 64 per GPU on eight of them) on THIS one GPU:
+            # the same generator, global stream ids 0..511, everything resident in HBM (178 GB at F = 1000), one launch.
+            free_b, _tot = torch.cuda.mem_get_info()
+            need_b = 512 * n * 4 * 1.10 + (4 << 30)
+            if free_b < need_b:
+                return {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, {need_b / 1e9:.0f} GB needed"}
+            else:
+                big = amd.Demod(512, max_samples=n + 64, streaming=True, device=dev_index)
+                d_big, tx_big, _n = workload.generate(amd, big, torch, dev, range(512), F, args.ebn0)
+                big.enable_timing(True)
+                for rep in range(2):
+                    big.reset()
+                    for k in range(512):
+                        big.attach(k, d_big[k].data_ptr(), n, eof=True)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    big.process()
+                    big.sync()
                     t1 = time.perf_counter() - t0
-                f_, m_, c_, cap_ = m.device_frames()
-                cnt = torch.as_tensor(DevPtr(c_, (ns,), "<i4"), device=dev).cpu().numpy()
-                fe_ms = m.kernel_times()["msk_frontend"]
-                ent[f"{spw}_per_wave"] = {"Msamples/s": round(ns * sub_n / t1 / 1e6, 1), "ms": round(t1 * 1e3, 2),
-                                          "frontend_alone_Msamples/s": round(ns * sub_n / fe_ms / 1e3, 1),
-                                          "frames_released": int(cnt.sum())}
-            sweep[f"{ns}x{nfr}"] = ent
-            m.close()
-        extras["stream_sweep"] = sweep
-        # PCIe-inclusive: the boundary's host-buffer entry points instead of HBM-resident captures. Pinned host copies of the
-        # first FH frames of every stream are pushed in rounds of RH frames: "host_pushed" with one opv_push_iq per stream (a copy
-        # each, on the library's copy stream), "host_pushed_batched" with one opv_push_iq_batch_async per round (ONE gather kernel
-        # for the 64 blocks; opv_process queues behind it on the device) - either way round r + 1 crosses PCIe while the kernels
-        # of round r run. Same streams attached in HBM are timed beside it.
-        FH, RH = min(F, 100), 10
-        if FH >= 2 * RH:
-            sub_n = FH * FRAME_SAMPLES
-            host = [d_iq[k][: 2 * sub_n].cpu().pin_memory() for k in range(S)]
-            host_np = [h.numpy() for h in host]
-            hp = amd.Demod(S, max_samples=sub_n + 64, streaming=True, device=dev_index)
-            res = {}
-            for mode in ("hbm_attached", "host_pushed", "host_pushed", "host_pushed_batched", "host_pushed_batched"):
-                hp.reset()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                if mode == "hbm_attached":
-                    for k in range(S):
-                        hp.attach(k, d_iq[k].data_ptr(), sub_n, eof=True)
-                    hp.process()
-                else:
-                    per = RH * FRAME_SAMPLES
-                    for r in range(0, sub_n, per):
-                        m = min(per, sub_n - r)
-                        if mode == "host_pushed_batched":
-                            hp.push_batch(range(S), [host_np[k][2 * r: 2 * (r + m)] for k in range(S)], wait=False)
-                        else:
-                            for k in range(S):
-                                hp.push(k, host_np[k][2 * r: 2 * (r + m)])
+                fv, cv = workload.frame_views(big, torch, dev)
+                ok_counts = bool((cv == F).all().item())
+                exp_b = torch.from_numpy(tx_big).to(dev)
+                n_bad = int((fv[:, :F, :] != exp_b).any(dim=2).sum().item())
+                res_big = {
+                    "streams": 512, "frames_per_stream": F, "iq_GB_in_hbm": round(512 * n * 4 / 1e9, 1),
+                    "Msamples/s": round(512 * n / t1 / 1e6, 1), "x_realtime": round(512 * n / t1 / 2.168e6, 0), "ms": round(t1 * 1e3, 2),
+                    "kernel_ms": {k: round(v, 3) for k, v in big.kernel_times().items()},
+                    "every_stream_released_all_frames": ok_counts, "frames_exact": 512 * F - n_bad, "frames_total": 512 * F}
+                big.close()
+                del d_big, fv, cv, exp_b
+                torch.cuda.empty_cache()
+            return res_big
+        if not args.no_big and S == 64:
+            put("configs4_workload_on_one_gpu", 24.0, x_configs4)
+
+        def x_many():
+            # The many-stream regime on data of its own (not carved out of the 64 captures): 32 768 independent streams x 8 frames,
+            # every one its own BERT capture through the device channel (91 GB of IQ in HBM), one opv_process on the automatic
+            # mapping - sixteen streams per wavefront, two waves per SIMD (k_frontend_x16.hip). The only place where this path's
+            # HBM fraction is not negligible: reported with its own roofline figures.
+            NS, NF = 32768, 8
+            n8 = amd.lib().opv_tx_modulated_samples(NF)
+            free_b, _tot = torch.cuda.mem_get_info()
+            need_b = NS * n8 * 4 * 1.05 + (12 << 30)
+            if free_b < need_b:
+                return {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, {need_b / 1e9:.0f} GB needed"}
+            else:
+                ms = amd.Demod(NS, max_samples=n8 + 64, streaming=True, device=dev_index)
+                gt = {}
+                d_ms, tx_ms, _n8 = workload.generate(amd, ms, torch, dev, range(NS), NF, args.ebn0, timing=gt)
+                ms.enable_timing(True)
+                for rep in range(2):
+                    ms.reset()
+                    for k in range(NS):
+                        ms.attach(k, d_ms[k].data_ptr(), n8, eof=True)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    ms.process()
+                    ms.sync()
+                    t1 = time.perf_counter() - t0
+                fv, cv = workload.frame_views(ms, torch, dev)
+                exp_m = torch.from_numpy(tx_ms).to(dev)
+                n_bad = int((fv[:, :NF - 1, :] != exp_m[:, :NF - 1, :]).any(dim=2).sum().item())
+                ktm = ms.kernel_times()
+                fe_gbs = NS * n8 * ALGO_BYTES_PER_SAMPLE / (ktm["msk_frontend"] * 1e-3) / 1e9
+                res_many = {
+                    "streams": NS, "frames_per_stream": NF, "iq_GB_in_hbm": round(NS * n8 * 4 / 1e9, 1), "generate_s": round(gt["generate_s"], 1),
+                    "frontend_kernel": ms.frontend_kernel(),
+                    "Msamples/s": round(NS * n8 / t1 / 1e6, 1), "x_realtime": round(NS * n8 / t1 / 2.168e6, 0), "ms": round(t1 * 1e3, 2),
+                    "frontend_alone_Msamples/s": round(NS * n8 / ktm["msk_frontend"] / 1e3, 1),
+                    "kernel_ms": {k: round(v, 3) for k, v in ktm.items()},
+                    "roofline_frontend": {"bound": "hbm", "achieved": round(fe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": round(fe_gbs / HBM_PEAK_GBS, 4)},
+                    "frames_released": int(cv.sum().item()), "frames_exact_of_first_7": NS * (NF - 1) - n_bad, "frames_compared": NS * (NF - 1)}
+                ms.close()
+                del d_ms, fv, cv, exp_m
+                torch.cuda.empty_cache()
+            return res_many
+        if not args.no_big and S == 64:
+            put("many_streams_unique_captures", 24.0, x_many)
+
+        def x_pcie():
+            # PCIe-inclusive: the boundary's host-buffer entry points instead of HBM-resident captures. Pinned host copies of the
+            # first FH frames of every stream are pushed in rounds of RH frames: "host_pushed" with one opv_push_iq per stream (a copy
+            # each, on the library's copy stream), "host_pushed_batched" with one opv_push_iq_batch_async per round (ONE gather kernel
+            # for the 64 blocks; opv_process queues behind it on the device) - either way round r + 1 crosses PCIe while the kernels
+            # of round r run. Same streams attached in HBM are timed beside it. Then a live serving round.
+            both = {}
+            FH, RH = min(F, 100), 10
+            if FH >= 2 * RH:
+                sub_n = FH * FRAME_SAMPLES
+                host = [d_iq[k][: 2 * sub_n].cpu().pin_memory() for k in range(S)]
+                host_np = [h.numpy() for h in host]
+                hp = amd.Demod(S, max_samples=sub_n + 64, streaming=True, device=dev_index)
+                res = {}
+                for mode in ("hbm_attached", "host_pushed", "host_pushed", "host_pushed_batched", "host_pushed_batched"):
+                    hp.reset()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    if mode == "hbm_attached":
+                        for k in range(S):
+                            hp.attach(k, d_iq[k].data_ptr(), sub_n, eof=True)
                         hp.process()
-                    if mode == "host_pushed_batched":
-                        hp.push_wait()
-                    for k in range(S):
-                        hp.flush(k)
-                    hp.process()
-                hp.sync()
-                t1 = time.perf_counter() - t0
-                f_, m_, c_, cap_ = hp.device_frames()
-                cnt = torch.as_tensor(DevPtr(c_, (S,), "<i4"), device=dev).cpu().numpy()
-                res[mode] = {"Msamples/s": round(S * sub_n / t1 / 1e6, 1), "ms": round(t1 * 1e3, 2),
-                             "GB/s_over_pcie": None if mode == "hbm_attached" else round(S * sub_n * 4 / t1 / 1e9, 2),
-                             "frames_released": int(cnt.sum())}
-                if mode != "hbm_attached":     # the pushed streams are fresh (reset drops the attachment)
-                    fr_h = torch.as_tensor(DevPtr(f_, (S, cap_, 134), "|u1"), device=dev)[:, : FH - 1, :]
-                    assert bool((fr_h == frames_view[:, : FH - 1, :]).all().item()), "pushed-path frames differ from the attached run"
-            res["config"] = f"{S} streams x {FH} frames, rounds of {RH} frames, pinned host buffers"
-            extras["pcie_inclusive"] = res
-            hp.close()
-            # live serving round: one 86720-sample chunk (40 ms of signal) per stream pushed from host memory,
-            # processed, frames popped - what a multi-stream receiver does every 40 ms
-            lv = amd.Demod(S, max_samples=4 * FRAME_SAMPLES + 65536, streaming=True, device=dev_index)
-            rounds = []
-            for r in range(min(14, FH - 1)):
-                blks = [host_np[k][2 * r * FRAME_SAMPLES: 2 * (r + 1) * FRAME_SAMPLES] for k in range(S)]
-                t0 = time.perf_counter()
-                lv.push_batch(range(S), blks)
-                t1 = time.perf_counter()
-                lv.process()
-                lv.sync()
-                t2 = time.perf_counter()
-                got = sum(len(lv.pop_frames(k)[0]) for k in range(S))
-                t3 = time.perf_counter()
-                rounds.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2, got))
-            med = lambda i: round(1e3 * float(np.median([x[i] for x in rounds[3:]])), 3)
-            extras["live_round"] = {"streams": S, "signal_ms_per_round": 40.0, "round_ms": med(0), "push_ms": med(1),
-                                    "process_ms": med(2), "pop_ms": med(3), "frames_per_round": int(rounds[-1][4])}
-            lv.close()
-            del host, host_np
-        tgt = [int(k.split("x")[0]) for k, v in sweep.items() if max(e["Msamples/s"] for e in v.values()) >= 21680.0]
-        extras["streams_for_target"] = {"target_Msamples/s": 21680.0, "smallest_swept_stream_count_meeting_it": min(tgt) if tgt else None,
-                                        "swept": sorted(int(k.split("x")[0]) for k in sweep)}
-        # BASELINE configs[4]'s whole workload (512 streams x F frames, 64 per GPU on eight of them) on THIS one GPU:
-        # the same generator, global stream ids 0..511, everything resident in HBM (178 GB at F = 1000), one launch.
-        if not args.no_big and S == 64:
-            try:
-                free_b, _tot = torch.cuda.mem_get_info()
-                need_b = 512 * n * 4 * 1.10 + (4 << 30)
-                if free_b < need_b:
-                    extras["configs4_workload_on_one_gpu"] = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, {need_b / 1e9:.0f} GB needed"}
-                else:
-                    big = amd.Demod(512, max_samples=n + 64, streaming=True, device=dev_index)
-                    d_big, tx_big, _n = workload.generate(amd, big, torch, dev, range(512), F, args.ebn0)
-                    big.enable_timing(True)
-                    for rep in range(2):
-                        big.reset()
-                        for k in range(512):
-                            big.attach(k, d_big[k].data_ptr(), n, eof=True)
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        big.process()
-                        big.sync()
-                        t1 = time.perf_counter() - t0
-                    fv, cv = workload.frame_views(big, torch, dev)
-                    ok_counts = bool((cv == F).all().item())
-                    exp_b = torch.from_numpy(tx_big).to(dev)
-                    n_bad = int((fv[:, :F, :] != exp_b).any(dim=2).sum().item())
-                    extras["configs4_workload_on_one_gpu"] = {
-                        "streams": 512, "frames_per_stream": F, "iq_GB_in_hbm": round(512 * n * 4 / 1e9, 1),
-                        "Msamples/s": round(512 * n / t1 / 1e6, 1), "x_realtime": round(512 * n / t1 / 2.168e6, 0), "ms": round(t1 * 1e3, 2),
-                        "kernel_ms": {k: round(v, 3) for k, v in big.kernel_times().items()},
-                        "every_stream_released_all_frames": ok_counts, "frames_exact": 512 * F - n_bad, "frames_total": 512 * F}
-                    big.close()
-                    del d_big, fv, cv, exp_b
-                    torch.cuda.empty_cache()
-            except Exception as e:                       # an extra must never cost the bench line
-                extras["configs4_workload_on_one_gpu"] = {"error": repr(e)[:300]}
-        # The many-stream regime on data of its own (not carved out of the 64 captures): 32 768 independent streams x 8 frames,
-        # every one its own BERT capture through the device channel (91 GB of IQ in HBM), one opv_process on the automatic
-        # mapping - sixteen streams per wavefront, two waves per SIMD (k_frontend_x16.hip). The only place where this path's
-        # HBM fraction is not negligible: reported with its own roofline figures.
-        if not args.no_big and S == 64:
-            try:
-                NS, NF = 32768, 8
-                n8 = amd.lib().opv_tx_modulated_samples(NF)
-                free_b, _tot = torch.cuda.mem_get_info()
-                need_b = NS * n8 * 4 * 1.05 + (12 << 30)
-                if free_b < need_b:
-                    extras["many_streams_unique_captures"] = {"skipped": f"{free_b / 1e9:.0f} GB of HBM free, {need_b / 1e9:.0f} GB needed"}
-                else:
-                    ms = amd.Demod(NS, max_samples=n8 + 64, streaming=True, device=dev_index)
-                    gt = {}
-                    d_ms, tx_ms, _n8 = workload.generate(amd, ms, torch, dev, range(NS), NF, args.ebn0, timing=gt)
-                    ms.enable_timing(True)
-                    for rep in range(2):
-                        ms.reset()
-                        for k in range(NS):
-                            ms.attach(k, d_ms[k].data_ptr(), n8, eof=True)
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        ms.process()
-                        ms.sync()
-                        t1 = time.perf_counter() - t0
-                    fv, cv = workload.frame_views(ms, torch, dev)
-                    exp_m = torch.from_numpy(tx_ms).to(dev)
-                    n_bad = int((fv[:, :NF - 1, :] != exp_m[:, :NF - 1, :]).any(dim=2).sum().item())
-                    ktm = ms.kernel_times()
-                    fe_gbs = NS * n8 * ALGO_BYTES_PER_SAMPLE / (ktm["msk_frontend"] * 1e-3) / 1e9
-                    extras["many_streams_unique_captures"] = {
-                        "streams": NS, "frames_per_stream": NF, "iq_GB_in_hbm": round(NS * n8 * 4 / 1e9, 1), "generate_s": round(gt["generate_s"], 1),
-                        "frontend_kernel": ms.frontend_kernel(),
-                        "Msamples/s": round(NS * n8 / t1 / 1e6, 1), "x_realtime": round(NS * n8 / t1 / 2.168e6, 0), "ms": round(t1 * 1e3, 2),
-                        "frontend_alone_Msamples/s": round(NS * n8 / ktm["msk_frontend"] / 1e3, 1),
-                        "kernel_ms": {k: round(v, 3) for k, v in ktm.items()},
-                        "roofline_frontend": {"bound": "hbm", "achieved": round(fe_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                              "frac": round(fe_gbs / HBM_PEAK_GBS, 4)},
-                        "frames_released": int(cv.sum().item()), "frames_exact_of_first_7": NS * (NF - 1) - n_bad, "frames_compared": NS * (NF - 1)}
-                    ms.close()
-                    del d_ms, fv, cv, exp_m
-                    torch.cuda.empty_cache()
-            except Exception as e:                       # an extra must never cost the bench line
-                extras["many_streams_unique_captures"] = {"error": repr(e)[:300]}
+                    else:
+                        per = RH * FRAME_SAMPLES
+                        for r in range(0, sub_n, per):
+                            m = min(per, sub_n - r)
+                            if mode == "host_pushed_batched":
+                                hp.push_batch(range(S), [host_np[k][2 * r: 2 * (r + m)] for k in range(S)], wait=False)
+                            else:
+                                for k in range(S):
+                                    hp.push(k, host_np[k][2 * r: 2 * (r + m)])
+                            hp.process()
+                        if mode == "host_pushed_batched":
+                            hp.push_wait()
+                        for k in range(S):
+                            hp.flush(k)
+                        hp.process()
+                    hp.sync()
+                    t1 = time.perf_counter() - t0
+                    f_, m_, c_, cap_ = hp.device_frames()
+                    cnt = torch.as_tensor(DevPtr(c_, (S,), "<i4"), device=dev).cpu().numpy()
+                    res[mode] = {"Msamples/s": round(S * sub_n / t1 / 1e6, 1), "ms": round(t1 * 1e3, 2),
+                                 "GB/s_over_pcie": None if mode == "hbm_attached" else round(S * sub_n * 4 / t1 / 1e9, 2),
+                                 "frames_released": int(cnt.sum())}
+                    if mode != "hbm_attached":     # the pushed streams are fresh (reset drops the attachment)
+                        fr_h = torch.as_tensor(DevPtr(f_, (S, cap_, 134), "|u1"), device=dev)[:, : FH - 1, :]
+                        assert bool((fr_h == frames_view[:, : FH - 1, :]).all().item()), "pushed-path frames differ from the attached run"
+                res["config"] = f"{S} streams x {FH} frames, rounds of {RH} frames, pinned host buffers"
+                both["pcie_inclusive"] = res
+                hp.close()
+                # live serving round: one 86720-sample chunk (40 ms of signal) per stream pushed from host memory,
+                # processed, frames popped - what a multi-stream receiver does every 40 ms
+                lv = amd.Demod(S, max_samples=4 * FRAME_SAMPLES + 65536, streaming=True, device=dev_index)
+                rounds = []
+                for r in range(min(14, FH - 1)):
+                    blks = [host_np[k][2 * r * FRAME_SAMPLES: 2 * (r + 1) * FRAME_SAMPLES] for k in range(S)]
+                    t0 = time.perf_counter()
+                    lv.push_batch(range(S), blks)
+                    t1 = time.perf_counter()
+                    lv.process()
+                    lv.sync()
+                    t2 = time.perf_counter()
+                    got = sum(len(lv.pop_frames(k)[0]) for k in range(S))
+                    t3 = time.perf_counter()
+                    rounds.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2, got))
+                med = lambda i: round(1e3 * float(np.median([x[i] for x in rounds[3:]])), 3)
+                both["live_round"] = {"streams": S, "signal_ms_per_round": 40.0, "round_ms": med(0), "push_ms": med(1),
+                                        "process_ms": med(2), "pop_ms": med(3), "frames_per_round": int(rounds[-1][4])}
+                lv.close()
+                del host, host_np
+            return both
+        both = budget.run("pcie_inclusive+live_round", 10.0, x_pcie)
+        if both is not None:
+            extras.update(both if "error" not in both else {"pcie_inclusive": both})
+        put("cli_drop_in", 9.0, lambda: cli_drop_in(raw, n))
         if not args.no_big:
-            try:
-                extras["live_capacity"] = live_capacity(dev_index)
-            except Exception as e:                       # an extra must never cost the bench line
-                extras["live_capacity"] = {"error": repr(e)[:300]}
+            put("live_capacity", 26.0, lambda: live_capacity(dev_index, budget))
+        extras["budget"] = budget.report()
+        extras["skipped_for_budget"] = budget.skipped
         out["extras"] = extras
-        base = d_base.cpu().numpy()
-        raw = base.tobytes()
-        out["cpu_baseline"] = cpu_baseline(raw, n)
-        out["extras"]["cli_drop_in"] = cli_drop_in(raw, n)
-        out["extras"]["cpu_baseline_all_cores"] = cpu_all_cores(raw, n)
         out["setup"] = {"device_modulate_s_all_streams": round(t_mod, 2),
                         "device_modulate_one_stream": {"s": round(t_dev_mod, 3), "Msamples/s": round(n / t_dev_mod / 1e6, 1),
                                                         "note": "opv_tx_modulate_device end to end on a fresh context: 134 B/frame H2D, k_tx_encode, k_tx_scan_frames, "

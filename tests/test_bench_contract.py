@@ -1,7 +1,9 @@
 """CPU-only: the shape of bench.py's ONE JSON line (the driver's contract), checked on the line recorded on MI355X by
-profiles/collect.sh (profiles/r03_bench.json): metric / config as BASELINE.json names them, whole-job value, the roofline and
-cpu_baseline objects with every field the contract lists, internally consistent numbers."""
+profiles/collect.sh (the newest profiles/rNN_bench.json; made with an extras budget that holds every extra): metric / config as
+BASELINE.json names them, whole-job value, the roofline and cpu_baseline objects with every field the contract lists,
+internally consistent numbers."""
 import json
+import re
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -39,6 +41,10 @@ def test_recorded_bench_line_has_the_contract_shape():
     assert b["bound"] == "wave-issue" and b["waves"] == 64 and b["simds"] == 1024
     assert 0.5 < b["frac"] <= 1.0 and abs(b["frac"] - b["achieved"] / b["peak"]) < 2e-3 and b["frac"] == r["issue"]["wave_issue_frac"]
     assert b["frac"] > 100 * r["frac"]                                   # (what the HBM fraction alone would hide)
+    # ... and it is the FIRST thing the note says: a record that keeps the note's first hundred characters keeps the binding bound
+    m_ = re.match(r"binding=wave-issue (0\.\d{3}) \((\d+) instr x 4 / ([\d.]+) cyc\); ", r["note"])
+    assert m_, r["note"][:120]
+    assert float(m_.group(1)) == round(b["frac"], 3) and abs(float(m_.group(3)) - b["peak"]) < 0.05 and abs(4 * int(m_.group(2)) - b["achieved"]) <= 2.0
     assert r["fp64_valu"]["peak"] == 78.6 and r["fp64_valu"]["unit"] == "TFLOP/s"
     c = line["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
@@ -47,9 +53,15 @@ def test_recorded_bench_line_has_the_contract_shape():
     assert line["check"]["edge_ties"] == 0 and line["check"]["frames_exact"] >= 0.99 * line["check"]["frames_total"]
     ac = line["extras"]["all_clean_variant"]                              # C4's "all-clean variant": every frame exact and perfect
     assert ac["frames_exact"] == ac["frames_total"] == ac["frames_perfect"] == 64000 and ac["steps"] >= 5
+    # the extras share one wall-clock budget; the recorded line was made with one that holds them all
+    assert line["extras"]["skipped_for_budget"] == [] and line["extras"]["budget"]["spent_total_s"] <= line["extras"]["budget"]["seconds"]
     lc = line["extras"]["live_capacity"]
     assert lc["streams"] >= 4096 and lc["round_ms_p99"] < 40.0 and all(p.get("frames_wrong", 0) == 0 for p in lc["probes"])
-    assert lc["pipelined"]["streams"] >= lc["streams"]
+    assert lc["pipelined"]["streams"] >= lc["streams"] and lc["cut_short"] is None
+    # the boundary's host-buffer entry points: the batched asynchronous push releases what the attached run releases, faster than one copy per stream
+    pi = line["extras"]["pcie_inclusive"]
+    assert pi["host_pushed_batched"]["frames_released"] == pi["host_pushed"]["frames_released"] == pi["hbm_attached"]["frames_released"]
+    assert pi["host_pushed_batched"]["ms"] < pi["host_pushed"]["ms"]
     # the regimes beside the contract configuration, as recorded: a host-side step that grows with the stream count shows here first
     # (round 5: deciding EVERY guarded offset search on the host took the 32 768-stream figure from 412 to 264 GS/s)
     ex = line["extras"]
