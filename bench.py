@@ -24,7 +24,7 @@ Also reported (same run, outside the timed steps): the reference `opv-demod -s -
 (cpu_baseline.kind = "reference") when the prebuilt oracle/_ref binary travelled with the snapshot, else the C oracle
 ("port") - always - and the EXTRAS: configs[1] (ONE clean 1000-frame stream), the all-clean variant, a many-short-streams
 sweep that shows the throughput-bound regime, configs[4]'s whole workload on one GPU, 32 768 unique streams, the
-PCIe-inclusive rates, the live-serving capacity. The extras share ONE wall-clock budget (--extras-budget, default 70 s): they
+PCIe-inclusive rates, the live-serving capacity. The extras share ONE wall-clock budget (--extras-budget, default 75 s): they
 run in a fixed order of priority, each only if its estimated cost still fits, and extras.skipped_for_budget names the ones
 that did not (profiles/collect.sh records the line with a budget that holds them all).
 """
@@ -167,27 +167,29 @@ def live_capacity(dev_index, budget=None):
     C++ caller of the C ABI like opv-rx-bridge) runs 120 serving rounds - one 86 720-sample chunk per stream pushed from pinned host
     memory over PCIe (every stream's chunk at its own host addresses: N x 347 KB of distinct memory per round), opv_process, every
     stream's frames popped and compared with what was sent - and reports the round-time distribution; the capacity is the largest N
-    probed whose p99 round stays under the 40 ms of signal a round consumes. Bisection of [1024, 8192] to 512 streams for the serial
-    loop (push, process, pop), then of [that, that + 2048] for the double-buffered one (opv_push_iq_batch_async: round r + 1
-    crosses PCIe while round r is processed and popped): about eight probes of ~9 s where the doubling + linear walk of round 5 took
-    fifteen. Every probe is charged to the extras' budget; when that runs out the search ends with the best bracket it has
-    ("cut_short")."""
+    probed whose p99 round stays under the 40 ms of signal a round consumes, to 256 streams - for the serial loop (push, process,
+    pop) and for the double-buffered one (opv_push_iq_batch_async: round r + 1 crosses PCIe while round r is processed and
+    popped). A round is bound by the PCIe link, so its time is linear in N: every probe's p99 predicts the capacity and the next
+    probe goes there (a secant search; three probes for the serial loop, two for the pipelined one, where the doubling + linear
+    walk of round 5 took thirteen). Every probe is charged to the extras' budget - 60 rounds each while that is tight, 120 when
+    it is not; when it runs out the search ends with the best bracket it has ("cut_short")."""
     exe = ROOT / "opv-cxx-demod_amd" / "bin" / "opv-live-capacity"
     if not exe.exists():
         return None
     probes = {}
     t_end = time.perf_counter() + (budget.left() if budget is not None else 150.0)   # the whole search is bounded by the extras' budget
     cut = []
+    rounds = 120 if (budget is None or budget.left() > 150.0) else 60
 
     def probe(n, pipelined=False):
         key = (n, pipelined)
         if key not in probes:
             left = t_end - time.perf_counter()
-            if left < 12.0:                            # a probe: process start + 120 rounds of <= 40 ms + the check
+            if left < (12.0 if rounds == 120 else 8.0):   # a probe: process start + the rounds of <= 40 ms + the check
                 cut.append(n)
                 return None
             try:
-                p = subprocess.run([str(exe), str(n), "120", "6", str(dev_index)] + (["--pipelined"] if pipelined else []),
+                p = subprocess.run([str(exe), str(n), str(rounds), "6", str(dev_index)] + (["--pipelined"] if pipelined else []),
                                    capture_output=True, text=True, timeout=min(60.0, left))
                 line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
                 probes[key] = json.loads(line[-1]) if p.returncode == 0 and line else {"streams": n, "pipelined": pipelined, "error": (p.stderr or p.stdout)[-200:], "rc": p.returncode}
@@ -196,34 +198,31 @@ def live_capacity(dev_index, budget=None):
         r = probes[key]
         return "error" not in r and r["round_ms_p99"] < 40.0 and r["frames_wrong"] == 0
 
-    def bisect(lo, hi, pipelined, step=512):
-        """largest n in [lo, hi) on the grid of `step` that passes, given that lo is known (or assumed) to pass and hi to fail"""
-        while hi - lo > step:
-            mid = (lo + hi) // 2 // step * step
-            if mid <= lo or mid >= hi:
-                break
-            ok = probe(mid, pipelined)
+    def secant(start, pipelined, grid=256, most=6):
+        """(largest N probed that passes, smallest that fails) with the two `grid` apart, each probe placed where the last one's
+        p99 says the 40 ms line is (round time is linear in N)"""
+        lo, hi, n = 0, None, start
+        for _ in range(most):
+            ok = probe(n, pipelined)
             if ok is None:
                 break
             if ok:
-                lo = mid
+                lo = max(lo, n)
             else:
-                hi = mid
+                hi = n if hi is None else min(hi, n)
+            if hi is not None and hi - lo <= grid:
+                break
+            p99 = probes[(n, pipelined)].get("round_ms_p99")
+            nxt = int(n * 40.0 / p99 * (0.985 if ok else 1.0)) // grid * grid if p99 else (n * 2 if ok else n // 2)
+            nxt = max(nxt, lo + grid)
+            if hi is not None:
+                nxt = min(nxt, hi - grid)
+            if nxt <= lo or nxt > 16384:
+                break
+            n = nxt
         return lo, hi
-    lo, hi = 0, 8192
-    first = probe(1024)
-    if first:
-        lo, hi = bisect(1024, 8192, False)
-    plo, phi = 0, None
-    if lo and not cut:
-        plo, phi = lo, lo + 2048
-        ok = probe(phi, True)                          # does the double-buffered loop carry 2048 streams more?
-        if ok:
-            plo, phi = phi, None
-        elif ok is not None:
-            plo, phi = bisect(lo, phi, True)
-            if plo == lo and not probe(lo, True):      # (the bracket's lower end was an assumption)
-                plo = 0
+    lo, hi = secant(4096, False)
+    plo, phi = (secant(lo + 768, True) if lo and not cut else (0, None))
     best, pbest = probes.get((lo, False)), probes.get((plo, True))
     return {"streams": lo, "round_ms_p99": best["round_ms_p99"] if best else None, "round_ms_p50": best["round_ms_p50"] if best else None,
             "Msamples/s_sustained": round(lo * 2.168, 1), "first_n_over_40ms": hi,
@@ -232,7 +231,8 @@ def live_capacity(dev_index, budget=None):
                           "Msamples/s_sustained": round(plo * 2.168, 1),
                           "what": "the same rounds with opv_push_iq_batch_async: the next round's chunks cross PCIe while this round is processed and popped"},
             "probes": [probes[k] for k in sorted(probes)],
-            "what": "largest probed N with p99 round < 40 ms over 120 rounds: one 86720-sample chunk per stream from pinned host memory "
+            "rounds_per_probe": rounds,
+            "what": "largest probed N with p99 round < 40 ms over the probe's rounds: one 86720-sample chunk per stream from pinned host memory "
                     "(opv_push_iq_batch), opv_process + opv_sync, opv_pop_frames of every stream (bin/opv-live-capacity)"}
 
 
@@ -279,7 +279,7 @@ def main():
     ap.add_argument("--ebn0", type=float, default=16.0, help="dB; <=0 disables noise")
     ap.add_argument("--no-extras", action="store_true", help="skip configs[1], the sweep and the CPU baseline")
     ap.add_argument("--no-big", action="store_true", help="skip the 512-stream x F-frame single-GPU run of the extras (178 GB of HBM)")
-    ap.add_argument("--extras-budget", type=float, default=70.0,
+    ap.add_argument("--extras-budget", type=float, default=75.0,
                     help="wall-clock seconds for everything beyond the contract's line (the extras, in a fixed order of priority; "
                          "what does not fit is listed in extras.skipped_for_budget)")
     args = ap.parse_args()
@@ -611,7 +611,7 @@ def main():
             try:
                 d_cl, tx_cl, _n = workload.generate(amd, dm, torch, dev, mine, F, None, clean=True)
                 cl_s, cl_fe = [], []
-                for rep in range(1 + max(5, args.steps)):
+                for rep in range(1 + 5):
                     dm.reset()
                     for k in range(S):
                         dm.attach(k, d_cl[k].data_ptr(), n, eof=True)
@@ -640,7 +640,7 @@ def main():
                 step(check=False)                        # dm's frame buffer holds the contract workload's frames again (compared below)
             assert cl_cnt and cl_bad == 0, "all-clean variant: a decoded frame differs from the transmitted one"
             return res_clean
-        put("all_clean_variant", 14.0, x_all_clean)
+        put("all_clean_variant", 8.0, x_all_clean)
         put("cpu_baseline_all_cores", 5.0, lambda: cpu_all_cores(raw, n))
 
         def x_sweep():                                   # throughput-bound regime: many short streams carved out of the resident captures
@@ -682,7 +682,7 @@ def main():
                 sweep[f"{ns}x{nfr}"] = ent
                 m.close()
             return sweep
-        put("stream_sweep", 24.0, x_sweep)
+        put("stream_sweep", 5.0, x_sweep)
         if "stream_sweep" in extras and "error" not in extras["stream_sweep"]:
             sweep = extras["stream_sweep"]
             tgt = [int(k.split("x")[0]) for k, v in sweep.items() if max(e["Msamples/s"] for e in v.values()) >= 21680.0]
@@ -723,7 +723,7 @@ def main():
                 torch.cuda.empty_cache()
             return res_big
         if not args.no_big and S == 64:
-            put("configs4_workload_on_one_gpu", 24.0, x_configs4)
+            put("configs4_workload_on_one_gpu", 9.0, x_configs4)
 
         def x_many():
             # The many-stream regime on data of its own (not carved out of the 64 captures): 32 768 independent streams x 8 frames,
@@ -769,7 +769,7 @@ def main():
                 torch.cuda.empty_cache()
             return res_many
         if not args.no_big and S == 64:
-            put("many_streams_unique_captures", 24.0, x_many)
+            put("many_streams_unique_captures", 14.0, x_many)
 
         def x_pcie():
             # PCIe-inclusive: the boundary's host-buffer entry points instead of HBM-resident captures. Pinned host copies of the
@@ -842,12 +842,12 @@ def main():
                 lv.close()
                 del host, host_np
             return both
-        both = budget.run("pcie_inclusive+live_round", 10.0, x_pcie)
+        both = budget.run("pcie_inclusive+live_round", 5.0, x_pcie)
         if both is not None:
             extras.update(both if "error" not in both else {"pcie_inclusive": both})
-        put("cli_drop_in", 9.0, lambda: cli_drop_in(raw, n))
+        put("cli_drop_in", 3.0, lambda: cli_drop_in(raw, n))
         if not args.no_big:
-            put("live_capacity", 26.0, lambda: live_capacity(dev_index, budget))
+            put("live_capacity", 18.0, lambda: live_capacity(dev_index, budget))
         extras["budget"] = budget.report()
         extras["skipped_for_budget"] = budget.skipped
         out["extras"] = extras

@@ -58,7 +58,7 @@ PY
 # the un-profiled bench line LAST, with this collection's traffic / instruction counts in place (bench.py reads the newest
 # profiles/rNN_traffic.json and attaches it when kernel and workload match)
 cp $O/${TAG}_traffic.json $R/profiles/${TAG}_traffic.json
-# (--extras-budget 600: every extra runs, extras.skipped_for_budget stays empty; the driver's own run keeps the 70 s default.
+# (--extras-budget 600: every extra runs, extras.skipped_for_budget stays empty; the driver's own run keeps the 75 s default.
 # The default run is recorded beside it: what the driver's record will look like, and how long it takes end to end.)
 timeout 900 python3 $R/bench.py --extras-budget 600 2>$O/bench.err | tail -1 > $O/${TAG}_bench.json
 ( time timeout 600 python3 $R/bench.py --steps 20 --warmup 5 2>$O/bench_default.err | tail -1 > $O/${TAG}_bench_default_budget.json ) 2> $O/${TAG}_bench_default_budget.time
