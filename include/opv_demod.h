@@ -270,6 +270,11 @@ int opv_offset_ties_on_host(opv_ctx* ctx);
 /* Streams whose tie the host has decided so far in this context (they are decided in stream order behind their search kernel,
  * opv_process does not wait for them: the number is final for a round after opv_sync). Diagnostic. */
 uint64_t opv_offset_ties_decided_on_host(opv_ctx* ctx);
+/* Streams that were listed for the host beyond what one round stages (8 passes x min(n_streams, 512) slots = up to 4096 streams of
+ * ONE context whose search ties at the last-place level in ONE round) and therefore kept the device's decision, as under
+ * opv_offset_ties_on_host() == 0. Exact mirror ties (real-valued captures: the one systematic source) come out the same either
+ * way; for others this is a parity class to report. 0 in every test and bench run. Diagnostic. */
+uint64_t opv_offset_ties_left_to_device(opv_ctx* ctx);
 
 /* Where and how fast the wavefront that served `stream` ran in the LAST front-end launch (with four streams per
  * wave, the four share these numbers): out[0] = HW_REG_HW_ID, out[1] = HW_REG_XCC_ID, out[2] = shader-clock cycles (s_memtime) and

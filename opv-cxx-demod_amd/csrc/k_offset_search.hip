@@ -313,12 +313,13 @@ extern "C" __global__ __launch_bounds__(256) void k_offset_search(OpvStream* __r
 
 // ---- the host's tie decision, in stream order (see the header; opv_capi.hip enqueues collect -> host function -> apply) -------
 // Pass `pass` serves entries [pass * slots, (pass + 1) * slots) of the tie list: one workgroup per slot copies the stream's
-// polynomial, power, window count and first nsym x 40 samples into pinned host memory (16 B per lane over PCIe).
+// polynomial, power, window count and first nsym x 40 samples into pinned host memory (16 B per lane over PCIe). The last pass
+// of a round also reports how many listed streams lie beyond it (their device decision stands; counted by the host function).
 extern "C" __global__ __launch_bounds__(256) void k_tie_collect(const OpvStream* __restrict__ streams, const uint32_t* __restrict__ tie_list,
-                                                                 uint32_t pass, uint32_t slots, OpvTieStage* __restrict__ stage) {
+                                                                 uint32_t pass, uint32_t slots, uint32_t last_pass, OpvTieStage* __restrict__ stage) {
     const uint32_t listed = tie_list[0], first = pass * slots;
     const uint32_t n = listed > first ? (listed - first < slots ? listed - first : slots) : 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { stage->n = n; stage->listed = listed; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stage->n = n; stage->listed = listed; stage->beyond = (last_pass && listed > first + n) ? listed - first - n : 0u; }
     if (blockIdx.x >= n) return;
     const uint32_t s = tie_list[1 + first + blockIdx.x];
     const OpvStream& st = streams[s];

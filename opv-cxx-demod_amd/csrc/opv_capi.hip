@@ -25,7 +25,7 @@
 #include "opv_tx_internal.h"
 
 extern "C" __global__ void k_offset_search(OpvStream*, OpvGlobalCfg, const double*, uint32_t*);
-extern "C" __global__ void k_tie_collect(const OpvStream*, const uint32_t*, uint32_t, uint32_t, OpvTieStage*);
+extern "C" __global__ void k_tie_collect(const OpvStream*, const uint32_t*, uint32_t, uint32_t, uint32_t, OpvTieStage*);
 extern "C" __global__ void k_tie_apply(OpvStream*, const OpvTieStage*, uint32_t, int);
 extern "C" __global__ void k_msk_frontend_rb(OpvStream*, OpvGlobalCfg, int);
 extern "C" __global__ void k_msk_frontend_rb_wg4(OpvStream*, OpvGlobalCfg, int);
@@ -234,6 +234,7 @@ struct opv_ctx {
         OpvTieStage* stage = nullptr;   // pinned: header + tie_slots slots
         uint32_t slots = 0;
         std::atomic<uint64_t> decided{0};   // streams the host has decided so far (opv_offset_ties_decided_on_host)
+        std::atomic<uint64_t> left{0};      // streams listed beyond what a round's passes stage: the device's decision stood (opv_offset_ties_left_to_device)
     } tie;
     std::vector<int> search_now;        // streams whose offset search can run in the round being enqueued
     // opv_push_iq_batch: the table of the gather kernel / of the batched compaction, in pinned memory (the kernels read it in place)
@@ -783,6 +784,7 @@ static void tie_host_fn(void* p) {
     opv_ctx::TieWork* w = (opv_ctx::TieWork*)p;
     uint32_t n = w->stage->n;
     if (n > w->slots) n = w->slots;
+    if (w->stage->beyond) w->left.fetch_add(w->stage->beyond, std::memory_order_relaxed);   // (the round's last pass reports what no pass staged)
     if (n == 0) return;
     opv_offset_decide_slots(w->stage->slot, n);
     w->decided.fetch_add(n, std::memory_order_relaxed);
@@ -847,11 +849,18 @@ extern "C" int opv_process(opv_ctx* c) {
     // near-ties are decided with the host's libm before the front-end takes the estimate, IN STREAM ORDER: per pass of
     // tie.slots listed streams a kernel stages their inputs in pinned memory, a host function decides them
     // (opv_offset_host.cpp), a kernel carries the results back. At most n_search streams can be listed, hence the number of
-    // passes; a pass nobody is listed for costs the stream ~25 us (scripts/microbench/hostfunc.hip). The caller never waits.
+    // passes - but never more than OPV_TIE_PASSES_MAX (8 x 512 = 4096 listed streams per round): a pass nobody is listed for
+    // costs the stream ~30 us (scripts/microbench/hostfunc.hip), a 32 768-stream round would pay for 64 of them, and a
+    // last-place tie that is NOT an exact mirror happens to about one stream in ten thousand (exact mirrors - real-valued
+    // captures, the one systematic source - come out the same on the device: test_offset_search_ties_decided_like_the_reference
+    // runs both paths). Streams listed beyond that keep the device's decision and are counted (opv_offset_ties_left_to_device).
+    // The caller never waits.
     if (host_ties) {
-        const uint32_t K = c->tie.slots, passes = (uint32_t)((n_search + K - 1) / K);
+        const uint32_t K = c->tie.slots;
+        uint32_t passes = (uint32_t)((n_search + K - 1) / K);
+        if (passes > OPV_TIE_PASSES_MAX) passes = OPV_TIE_PASSES_MAX;
         for (uint32_t p = 0; p < passes; ++p) {
-            k_tie_collect<<<K, 256, 0, c->stream>>>(c->d_streams, c->d_tie_list, p, K, c->tie.stage);
+            k_tie_collect<<<K, 256, 0, c->stream>>>(c->d_streams, c->d_tie_list, p, K, p + 1 == passes ? 1u : 0u, c->tie.stage);
             HIPCHK(hipLaunchHostFunc(c->stream, tie_host_fn, &c->tie));
             k_tie_apply<<<K, 192, 0, c->stream>>>(c->d_streams, c->tie.stage, K, S);
         }
@@ -1134,6 +1143,7 @@ extern "C" int opv_tap_offset_energies(opv_ctx* c, int s, double* out134) {
 
 extern "C" int opv_offset_ties_on_host(opv_ctx* c) { return c && c->host_ties ? 1 : 0; }
 extern "C" uint64_t opv_offset_ties_decided_on_host(opv_ctx* c) { return c ? c->tie.decided.load(std::memory_order_relaxed) : 0; }
+extern "C" uint64_t opv_offset_ties_left_to_device(opv_ctx* c) { return c ? c->tie.left.load(std::memory_order_relaxed) : 0; }
 
 extern "C" int opv_tap_wave_info(opv_ctx* c, int s, uint64_t out[4]) {
     if (int r = check_stream(c, s)) return r;

@@ -108,7 +108,9 @@ struct OpvStream {
 // One slot per tied stream and pass, in PINNED host memory: k_tie_collect fills `stream` .. `iq`, a host function enqueued
 // behind it (hipLaunchHostFunc: no HIP call inside) fills `est` .. `energies`, k_tie_apply behind that carries them into the
 // stream's context before the front-end reads the estimate. Nothing waits on the host's side.
-#define OPV_TIE_SLOTS_MAX 256                 // slots per pass (41 MB of pinned memory at most; a context of S streams has min(S, 256))
+#define OPV_TIE_SLOTS_MAX 512                 // slots per pass (82 MB of pinned memory at most; a context of S streams has min(S, 512))
+#define OPV_TIE_PASSES_MAX 8                  // passes per round: 4096 streams whose search ties at the last-place level in ONE round of ONE context;
+                                              // what lies beyond (counted) keeps the device's decision - see opv_process
 struct OpvTieSlot {
     uint32_t stream;          // index of the stream in its context
     uint32_t nsym;            // 40-sample windows the search used (<= 1000)
@@ -123,7 +125,8 @@ struct OpvTieSlot {
 struct OpvTieStage {
     uint32_t n;               // slots filled in this pass
     uint32_t listed;          // streams on the tie list in this round (all passes)
-    uint32_t pad[2];
+    uint32_t beyond;          // the round's LAST pass: listed streams that no pass staged (0 otherwise)
+    uint32_t pad;
     OpvTieSlot slot[1];       // [slots]
 };
 

@@ -32,7 +32,7 @@ EXPORTS = [
     "opv_attach_device_iq", "opv_process", "opv_sync", "opv_set_frontend", "opv_reset_stream", "opv_pop_frames", "opv_pop_events",
     "opv_get_state", "opv_device_frames", "opv_hip_stream", "opv_comm_unique_id", "opv_comm_init", "opv_comm_init_all",
     "opv_comm_destroy", "opv_gather_frames", "opv_gather_frames_all", "opv_tap_soft", "opv_tap_chunks",
-    "opv_tap_offset_energies", "opv_offset_ties_on_host", "opv_offset_ties_decided_on_host", "opv_tap_wave_info", "opv_tap_occupancy", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_bert_frames", "opv_tx_modulated_samples",
+    "opv_tap_offset_energies", "opv_offset_ties_on_host", "opv_offset_ties_decided_on_host", "opv_offset_ties_left_to_device", "opv_tap_wave_info", "opv_tap_occupancy", "opv_decode_payloads", "opv_tx_bert_frame", "opv_tx_bert_frames", "opv_tx_modulated_samples",
     "opv_tx_modulate", "opv_tap_tx_checkpoints", "opv_frontend_kernel", "opv_channel_device", "opv_resample_device", "opv_enable_timing", "opv_kernel_times", "opv_tx_modulate_device", "opv_tx_modulate_device_to_host",
     "opv_tx_stream_create", "opv_tx_stream_reset", "opv_tx_stream_frames", "opv_tx_stream_tail", "opv_tx_stream_destroy", "opv_tap_tx_frame",
 ]
@@ -133,6 +133,8 @@ def lib():
         L.opv_offset_ties_on_host.argtypes = [C.c_void_p]
         L.opv_offset_ties_decided_on_host.restype = C.c_uint64
         L.opv_offset_ties_decided_on_host.argtypes = [C.c_void_p]
+        L.opv_offset_ties_left_to_device.restype = C.c_uint64
+        L.opv_offset_ties_left_to_device.argtypes = [C.c_void_p]
         L.opv_tap_occupancy.argtypes = [C.c_void_p, C.c_void_p]
         L.opv_decode_payloads.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
@@ -411,6 +413,10 @@ class Demod:
     def offset_ties_decided_on_host(self):
         """streams whose offset-search tie the host's libm has decided so far (final for a round after sync())"""
         return int(lib().opv_offset_ties_decided_on_host(self.h))
+
+    def offset_ties_left_to_device(self):
+        """streams listed for the host beyond what a round stages (their device decision stood); 0 in ordinary operation"""
+        return int(lib().opv_offset_ties_left_to_device(self.h))
 
     def wave_info(self, stream):
         """(HW_ID, XCC_ID, shader cycles, 100 MHz ticks) of the wave that ran the stream's last front-end launch"""

@@ -11,6 +11,37 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The suite's wall clock against the driver's limits (900 s for `pytest -m gpu`, a few minutes for `-m "not gpu"`): every run
+# ends with its total and its ten slowest tests, whatever the flags (the same list `--durations=10` would print; here it cannot be
+# forgotten). Nothing is asserted - DESIGN.md section 4 states the current totals.
+_T0 = {}
+_DUR = {}
+
+
+def _start_clock():
+    import time
+    _T0["t"] = time.time()
+
+
+def pytest_runtest_logreport(report):
+    _DUR[report.nodeid] = _DUR.get(report.nodeid, 0.0) + report.duration      # setup + call + teardown
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    import time
+    if not _DUR:
+        return
+    total = time.time() - _T0.get("t", time.time())
+    expr = config.getoption("markexpr", "") or ""
+    limit = 900.0 if ("gpu" in expr and "not gpu" not in expr) else None
+    tr = terminalreporter
+    tr.write_sep("-", "wall clock")
+    tr.write_line(f"session {total:.0f} s" + (f" of the driver's {limit:.0f} s for `-m gpu` ({100.0 * total / limit:.0f} %)" if limit else "") +
+                  f"; tests alone {sum(_DUR.values()):.0f} s; the ten slowest:")
+    for nodeid, d in sorted(_DUR.items(), key=lambda kv: -kv[1])[:10]:
+        tr.write_line(f"  {d:7.1f} s  {nodeid}")
+
+
 def run_rccl_selftest():
     """BASELINE configs[4]'s RCCL leg on ONE GPU: bench.py with OPV_BENCH_FORCE_DIST=1 takes its N > 1 path
     (init_process_group("nccl", device_id=...), sharding.gather_frames on the library's zero-copy device views,
@@ -38,6 +69,7 @@ def pytest_sessionstart(session):
     """On a GPU box, under -m gpu: the RCCL self-test child runs FIRST, before this process has touched the GPU
     (tests/test_gpu_multirank.py::test_bench_rccl_leg_executes_at_world_1 reads the result)."""
     import os
+    _start_clock()
     expr = session.config.getoption("markexpr", "") or ""
     if "gpu" not in expr or "not gpu" in expr or os.environ.get("OPV_SKIP_RCCL_SELFTEST"):
         return

@@ -408,7 +408,7 @@ def test_process_returns_without_waiting_in_a_search_round(amd, oracle, iq10):
         d.process()
         took.append(time.perf_counter() - t0)
         d.sync()
-        assert d.offset_ties_decided_on_host() == 3 * (rnd + 1)
+        assert d.offset_ties_decided_on_host() == 3 * (rnd + 1) and d.offset_ties_left_to_device() == 0
     d.enable_timing(True)
     d.reset(-1)
     for k in range(S):
@@ -427,6 +427,31 @@ def test_process_returns_without_waiting_in_a_search_round(amd, oracle, iq10):
     off, _ = oracle.estimate_offset(plain, energies=True)
     for k in (0, 4, 699, 701, 2046):
         assert d.state(k).est_offset_hz == off and d.state(k).offset_ties == 0, k
+    d.close()
+
+
+def test_more_ties_in_one_round_than_the_host_passes_stage(amd, oracle):
+    """A round stages at most 8 passes x 512 streams = 4096 tied streams for the host (csrc/opv_device.h); a context whose inputs
+    tie SYSTEMATICALLY - real-valued captures on every stream, the mirrored candidates tie exactly - can list more. 4200 streams
+    of one short real-valued capture in one batch-mode round: 4096 are decided by the host, 104 keep the device's decision and
+    are counted, and (an exact mirror tie survives any odd / even sin / cos) every estimate equals the oracle's either way."""
+    import torch
+    S, n = 4200, 4000
+    x = np.zeros(2 * n, np.int16)
+    x[0::2] = np.rint(9000 * np.cos(2 * np.pi * 36000.0 * np.arange(n) / 2168000.0 + 0.3))
+    off, e = oracle.estimate_offset(x, energies=True)
+    assert off in (-1530.0, 1530.0)                                  # (a convex, exactly symmetric landscape: the edges tie)
+    d_x = torch.from_numpy(x).to("cuda")
+    d = amd.Demod(S, max_samples=n + 64, streaming=False)
+    assert d.offset_ties_on_host()
+    for k in range(S):
+        d.attach(k, d_x.data_ptr(), n, eof=True)
+    d.process()
+    d.sync()
+    assert d.offset_ties_decided_on_host() == 4096 and d.offset_ties_left_to_device() == S - 4096
+    est = np.array([d.state(k).est_offset_hz for k in range(S)])
+    ties = np.array([d.state(k).offset_ties for k in range(S)])
+    assert np.all(est == off) and np.all(ties >= 2), (np.unique(est), ties.min())
     d.close()
 
 
