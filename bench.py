@@ -656,7 +656,7 @@ def main():
                 m.enable_timing(True)
                 ent = {}
                 for spw in (1, 4, 16):                      # streams per wavefront (opv_set_frontend)
-                    if spw == 4 and ns < 4096:         # (the four-per-wave mapping is the automatic choice from 2049 streams on, DESIGN.md §3.1)
+                    if spw == 4 and ns < 4096:         # (the four-per-wave mapping is the automatic choice from 2049 streams on, DESIGN.md §3.1 table)
                         continue
                     if spw == 16 and ns < 4096:        # (sixteen per wave: 1024 waves = one per SIMD need 16 384 streams)
                         continue

@@ -18,7 +18,7 @@
 // workgroup = one per SIMD of a CU by construction, see msk_frontend_x4_body), 81 ms for 8192 (two waves per SIMD):
 // front-end alone 228 GS/s at 4096 streams, 264 at 8192 (round 1: 87 / 130). The one-wave kernel runs 1024 streams at a
 // time in 23 ms per 30 frames: faster up to 2048 streams, slower from 2049 on, which is where the shim switches
-// (DESIGN.md §3.1).
+// (NOTEBOOK.md §3.1).
 //
 // Mapping (row r = lane / 16 serves stream 4*blockIdx.x + r, t = lane % 16):
 //   * lane t owns the interpolated samples Lam_j = L(pos + j - 10), j = t + 16 q, q = 0..3 (j < 60); the

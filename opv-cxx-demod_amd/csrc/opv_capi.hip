@@ -70,10 +70,10 @@ int fail(int code, const char* what, hipError_t e = hipSuccess) {
 // double up on SIMDs (k_frontend.hip: msk_frontend_body)
 constexpr uint64_t kScaleWaveMaxFrames = 4096;    // frames (upper estimate) per round up to which the scale pre-pass runs one wave per frame
 constexpr int kFrontendWg4MinStreams = 512;
-constexpr int kFrontendX16MinStreams = 8192;      // measured on MI355X: 8192 streams x 16 frames: four per wave 260 GS/s, sixteen per wave 247 (512 waves: half the SIMDs idle;
+constexpr int kFrontendX16MinStreams = 8192;      // measured on MI355X (NOTEBOOK.md §3.1): 8192 streams x 16 frames: four per wave 260 GS/s, sixteen per wave 247 (512 waves: half the SIMDs idle;
                                                   // with 7 frames per stream, bench.py's sweep, 221 / 255: the cross-over IS about 8192); 16 384 x 8: 187 / 478; 32 768 x 8: 204 / 574
 constexpr int kFrontendX16Wg8MinStreams = 16384;  // 1024 waves of sixteen streams = one per SIMD; beyond that eight waves (two per SIMD) per workgroup
-constexpr int kFrontendX4MinStreams = 2049;      // measured on MI355X: one wave per stream runs 1024 streams at a time (46 ms per 2048 x 30 frames, 69 ms from 2049 on), four per wave 4096 (47.5 ms)
+constexpr int kFrontendX4MinStreams = 2049;      // measured on MI355X (NOTEBOOK.md §3.1): one wave per stream runs 1024 streams at a time (46 ms per 2048 x 30 frames, 69 ms from 2049 on), four per wave 4096 (47.5 ms)
 
 struct StreamIn {  // host -> device per-round update
     const int16_t* iq;

@@ -88,7 +88,7 @@ def test_table_is_reproducible(tmp_path):
 
 def test_atan2_q3_table_is_within_its_stated_error(tmp_path):
     """opv_atan2_q3 (1025 rows, cubic: the one-wave front-end's angle from round 3 on): absolute error against glibc below
-    1e-13 rad over 4e6 random arguments, axes exact - the accuracy csrc/opv_atan2.h states and DESIGN.md prices (AFC steady
+    1e-13 rad over 4e6 random arguments, axes exact - the accuracy csrc/opv_atan2.h states and NOTEBOOK.md §3.1 prices (AFC steady
     state 3e-10 Hz, soft symbols 1e-17)."""
     c = tmp_path / "t.cpp"
     c.write_text(SRC.replace("OPV_FN(", "opv_atan2_q3("))
