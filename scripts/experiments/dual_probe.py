@@ -1,4 +1,5 @@
-"""dev: the two-waves-per-stream front-end on S streams x F frames: time, cycles per symbol, poll spins of each wave."""
+"""dev: one front-end mapping (1, 4 or 16 streams per wave; default 1) on S streams x F clean frames: front-end time, cycles per symbol.
+(Rounds 2 - 5 also ran the comparison mappings -1 / -2 through this script; those left the tree in round 6.)"""
 import sys, time
 from pathlib import Path
 import numpy as np
@@ -7,7 +8,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from __graft_entry__ import load_opv_amd
 amd = load_opv_amd()
 S, F = int(sys.argv[1]), int(sys.argv[2])
-mode = int(sys.argv[3]) if len(sys.argv) > 3 else -2
+mode = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 iq = amd.modulate(amd.bert_frames(F))
 n = iq.size // 2
 d_iq = torch.from_numpy(iq).cuda()
