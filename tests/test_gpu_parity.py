@@ -398,7 +398,7 @@ def test_process_returns_without_waiting_in_a_search_round(amd, oracle, iq10):
     d = amd.Demod(S, max_samples=n + 64, streaming=True)
     assert d.offset_ties_on_host()
     took = []
-    for rnd in range(3):                          # the first round also loads the code objects; the later ones are the measurement
+    for rnd in range(5):                          # the first round also loads the code objects; the later ones are the measurement (their minimum)
         if rnd:
             d.reset(-1)
         for k in range(S):
