@@ -444,8 +444,15 @@ extern "C" int opv_create(opv_ctx** out, int n_streams, const opv_cfg* cfg) {
     if (c->host_ties) {
         HIPCHK_C(hipMalloc(&c->d_tie_list, sizeof(uint32_t) * (S + 1)));
         c->tie.slots = (uint32_t)(S < (size_t)OPV_TIE_SLOTS_MAX ? S : (size_t)OPV_TIE_SLOTS_MAX);
-        HIPCHK_C(hipHostMalloc((void**)&c->tie.stage, offsetof(OpvTieStage, slot) + sizeof(OpvTieSlot) * c->tie.slots, hipHostMallocDefault));
-        c->tie.stage->n = c->tie.stage->listed = 0;
+        // (82 MB of pinned memory for 512 slots: a host that cannot pin that much keeps working - the device then decides the ties
+        // itself, and opv_offset_ties_on_host() says so)
+        if (hipHostMalloc((void**)&c->tie.stage, offsetof(OpvTieStage, slot) + sizeof(OpvTieSlot) * c->tie.slots, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            c->tie.stage = nullptr;
+            c->host_ties = false;
+        } else {
+            c->tie.stage->n = c->tie.stage->listed = c->tie.stage->beyond = 0;
+        }
     }
     HIPCHK_C(hipMemsetAsync(c->d_frames, 0, (size_t)OPV_FB * c->cap_frames * S, c->stream));
     HIPCHK_C(hipMemsetAsync(c->d_counts, 0, sizeof(int32_t) * S, c->stream));
