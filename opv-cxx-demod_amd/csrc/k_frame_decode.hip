@@ -110,8 +110,6 @@ __device__ __forceinline__ double payload_scale(const double* __restrict__ soft,
 // ---- packed 16-bit helpers: the two frames of a wave live in the two halves of every metric register ------------------
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b))); }
-typedef short ss2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_sign(uint32_t a) { return __builtin_bit_cast(uint32_t, (ss2)(__builtin_bit_cast(ss2, a) >> 15)); }   // 0xFFFF per negative half
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
 
 constexpr int kTabSteps = 24;                                     // steps per branch-metric table refill (four groups of six)

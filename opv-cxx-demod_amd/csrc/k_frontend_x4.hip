@@ -73,20 +73,6 @@ __device__ inline int dlo(double v) { return __double2loint(v); }
 __device__ inline int dhi(double v) { return __double2hiint(v); }
 __device__ inline double mkd(int hi, int lo) { return __hiloint2double(hi, lo); }
 
-template <int CTRL>
-__device__ inline double dpp_add(double v) {
-    const int lo = __builtin_amdgcn_mov_dpp(dlo(v), CTRL, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_mov_dpp(dhi(v), CTRL, 0xF, 0xF, true);
-    return v + mkd(hi, lo);
-}
-// sum over the 16 lanes of a DPP row, result in every lane of the row (row_ror 8, 4, 2, 1)
-__device__ inline double row_sum(double v) {
-    v = dpp_add<0x128>(v);
-    v = dpp_add<0x124>(v);
-    v = dpp_add<0x122>(v);
-    v = dpp_add<0x121>(v);
-    return v;
-}
 // four row sums in lockstep: a DPP read needs two wait states behind the VALU write of its source, and one sum's rotation
 // steps are a dependent chain (hipcc pads every step with s_nop 1) - the other three sums' instructions fill the slots
 template <int CTRL>
