@@ -430,6 +430,83 @@ def test_process_returns_without_waiting_in_a_search_round(amd, oracle, iq10):
     d.close()
 
 
+def test_tie_decision_in_stream_order_under_concurrency_async_push_and_early_destroy(amd, oracle, iq10):
+    """What the stream-ordered host decision (hipLaunchHostFunc between k_offset_search and the front-end) must survive besides
+    the plain case: (a) FOUR host threads, a context each, whose searches tie in the same moments - the host functions of four
+    HIP streams run on the runtime's threads at once, each spreading its slots over worker threads; (b) the tied captures
+    arriving through opv_push_iq_batch_async from pinned host memory with opv_process called BEFORE opv_push_wait - search,
+    staging kernel and host function all queue behind the move on the device; (c) opv_reset_stream and opv_destroy called right
+    behind opv_process, while the passes are still in flight (both drain the stream first). Estimates, energies and tie counts
+    equal the oracle's / the reference's first maximum everywhere."""
+    import threading
+    import torch
+    n = 86720
+    t = np.arange(n)
+    ties = []
+    for f_hz, amp, ph in ((33550.0, 9000.0, 0.3), (41000.0, 15000.0, 0.9), (52000.0, 4000.0, 2.2)):
+        x = np.zeros(2 * n, np.int16)
+        x[0::2] = np.rint(amp * np.cos(2 * np.pi * f_hz * t / 2168000.0 + ph))
+        ties.append(x)
+    plain = np.ascontiguousarray(iq10[: 2 * n])
+    caps = [ties[0], plain, ties[1], plain, ties[2], plain]
+    exp = [oracle.estimate_offset(x, energies=True) for x in (ties[0], plain, ties[1], ties[2])]
+    exp = {0: exp[0], 1: exp[1], 2: exp[2], 3: exp[1], 4: exp[3], 5: exp[1]}
+    pinned = []
+    for x in caps:
+        buf = torch.empty(x.size, dtype=torch.int16).pin_memory()
+        buf.numpy()[:] = x
+        pinned.append(buf)
+    out = [None] * 4
+
+    def work(k):
+        try:
+            res = []
+            for rep in range(4):
+                d = amd.Demod(len(caps), max_samples=n + 64, streaming=True)
+                assert d.offset_ties_on_host()
+                if rep % 2:                                           # (b) the first chunk arrives asynchronously from pinned memory
+                    d.push_batch(range(len(caps)), [b.numpy() for b in pinned], wait=False)
+                    d.process()
+                    d.push_wait()
+                else:
+                    for j, x in enumerate(caps):
+                        d.push(j, x)
+                    d.process()
+                if rep == 3:                                          # (c) destroy right behind the round: nothing may be left running
+                    d.close()
+                    continue
+                if rep == 2:                                          # (c) reset right behind the round, then the same round again
+                    d.reset(-1)
+                    for j, x in enumerate(caps):
+                        d.push(j, x)
+                    d.process()
+                d.sync()
+                res.append(([d.state(j).est_offset_hz for j in range(len(caps))], [d.state(j).offset_ties for j in range(len(caps))],
+                            [d.offset_energies(j) for j in range(len(caps))], d.offset_ties_decided_on_host(), d.offset_ties_left_to_device()))
+                d.close()
+            out[k] = res
+        except Exception as e:           # surfaces in the main thread below
+            out[k] = e
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for k in range(4):
+        assert not isinstance(out[k], Exception), out[k]
+        assert len(out[k]) == 3
+        for rep, (est, nt, taps, decided, left) in enumerate(out[k]):
+            assert left == 0 and decided == (6 if rep == 2 else 3), (k, rep, decided, left)     # (rep 2 ran the round twice)
+            for j in range(len(caps)):
+                off, e = exp[j]
+                assert est[j] == off, (k, rep, j, est[j], off)
+                if j % 2 == 0:
+                    assert nt[j] >= 2 and int(np.sum(taps[j] == e)) >= nt[j] - 1, (k, rep, j, nt[j])
+                else:
+                    assert nt[j] == 0, (k, rep, j)
+
+
 def test_more_ties_in_one_round_than_the_host_passes_stage(amd, oracle):
     """A round stages at most 8 passes x 512 streams = 4096 tied streams for the host (csrc/opv_device.h); a context whose inputs
     tie SYSTEMATICALLY - real-valued captures on every stream, the mirrored candidates tie exactly - can list more. 4200 streams
