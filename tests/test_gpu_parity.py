@@ -1700,6 +1700,34 @@ def test_host_cli_process_contract(amd, golden, iq10):
     assert "Demodulated 21780 symbols, final AFC offset: " in err                  # the reference's count (:462, :1173)
 
 
+def test_host_cli_on_a_capture_whose_offset_search_ties(amd, oracle, iq10):
+    """The tie decision in a plain C++ process (no Python, no torch: bin/opv-demod's own HIP runtime runs the host function): a
+    capture that opens with 40 000 REAL-valued samples - mirrored search candidates tie exactly, the reference keeps the first
+    maximum by its libm's last places - followed by the ten-frame BERT capture. `-s` and batch mode: the `Estimated carrier
+    offset` line equals what the oracle's estimate_offset says, and stdout + the whole stderr text equal the compiled reference
+    binary's where that travelled with the snapshot (oracle/_ref)."""
+    import subprocess
+    from oracle_lib import ref_binary
+    exe = str(ROOT / "opv-cxx-demod_amd" / "bin" / "opv-demod")
+    head = np.zeros(2 * 40000, np.int16)
+    head[0::2] = np.rint(12000 * np.cos(2 * np.pi * 36000.0 * np.arange(40000) / 2168000.0 + 0.3))
+    x = np.concatenate([head, iq10])
+    ref = ref_binary("opv-demod")
+    for args, streaming in ((["-s", "-r"], True), (["-r"], False)):
+        off = oracle.estimate_offset(x[: 2 * 86720] if streaming else x)
+        assert off in (-1530.0, 1530.0)                                   # the tied edge pair, dragged out by the fine pass
+        p = subprocess.run([exe] + args, input=x.tobytes(), capture_output=True, timeout=300)
+        err = p.stderr.decode()
+        assert f"Estimated carrier offset: {off:.1f} Hz\n" in err, err[:600]
+        if ref is not None:
+            q = subprocess.run([str(ref)] + args, input=x.tobytes(), capture_output=True, timeout=300)
+            assert p.returncode == q.returncode and p.stdout == q.stdout, args
+            mine, theirs = err.splitlines(), q.stderr.decode().splitlines()
+            assert len(mine) == len(theirs), args
+            for a, b in zip(mine, theirs):                                # (text equal but for the licensed last digit of raw=)
+                assert a == b or (a.split("raw=")[0] == b.split("raw=")[0] and "raw=" in a), (a, b)
+
+
 def test_host_cli_small_staging_buffer_and_a_backlog(amd, oracle, iq100):
     """bin/opv-demod takes up to eight chunks per round when stdin has a backlog - but never more than its staging buffer
     holds: with --capacity-sec 0.15 (3.75 chunks) and with 0.09 (2.2 chunks: no batching at all) a 30-frame capture read from
