@@ -868,7 +868,13 @@ extern "C" int opv_process(opv_ctx* c) {
         if (passes > OPV_TIE_PASSES_MAX) passes = OPV_TIE_PASSES_MAX;
         for (uint32_t p = 0; p < passes; ++p) {
             k_tie_collect<<<K, 256, 0, c->stream>>>(c->d_streams, c->d_tie_list, p, K, p + 1 == passes ? 1u : 0u, c->tie.stage);
-            HIPCHK(hipLaunchHostFunc(c->stream, tie_host_fn, &c->tie));
+            if (hipLaunchHostFunc(c->stream, tie_host_fn, &c->tie) != hipSuccess) {
+                // a runtime that cannot enqueue host functions: the round goes on with the device's decisions (the staging kernel
+                // left ties = 0 in every slot, so nothing would be applied anyway), and from now on the context says so
+                (void)hipGetLastError();
+                c->host_ties = false;
+                break;
+            }
             k_tie_apply<<<K, 192, 0, c->stream>>>(c->d_streams, c->tie.stage, K, S);
         }
     }
