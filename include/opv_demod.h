@@ -264,7 +264,8 @@ int opv_tap_offset_energies(opv_ctx* ctx, int stream, double* out134);
  * the reference's order of operations, are within 2e-13 of each other - what the last places of sin / cos can move - or equal,
  * src/opv-demod.cpp:161,195): 1 = the host, with the contenders evaluated by the reference's own loop on the
  * host's libm - opv_create found that this process's sin / cos reproduce a pinned reference energy (csrc/opv_offset_host.cpp);
- * 0 = the device's sincos (another libm on the host, or the test hook OPV_OFFSET_DISTRUST_LIBM, see opv_create): still the reference's order of
+ * 0 = the device's sincos (another libm on the host, a host that cannot pin the staging area or enqueue host functions, or the
+ * test hook OPV_OFFSET_DISTRUST_LIBM, see opv_create): still the reference's order of
  * operations, counted in offset_ties, but an exact tie is then decided by a different libm than the reference's. */
 int opv_offset_ties_on_host(opv_ctx* ctx);
 /* Streams whose tie the host has decided so far in this context (they are decided in stream order behind their search kernel,
