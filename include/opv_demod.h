@@ -21,7 +21,7 @@ extern "C" {
 #endif
 
 #define OPV_ABI_VERSION 7   /* 7: opv_process never waits on the host again - the host-libm decision of offset-search near-ties runs as a host
-                               function IN STREAM ORDER between the search and the front-end (+ opv_offset_ties_decided_on_host); opv_set_frontend
+                               function IN STREAM ORDER between the search and the front-end (+ opv_offset_ties_decided_on_host, opv_offset_ties_left_to_device); opv_set_frontend
                                takes 0 / 1 / 4 / 16 only (the comparison mappings are gone); opv_tap_occupancy's third entry is k_msk_frontend_x16_wg4;
                                6: offset-search near-ties are decided with the HOST's libm (opv_offset_ties_on_host), one host wait in the round
                                in which a stream's search runs; + opv_push_iq_batch_async / opv_push_wait; opv_push_iq_batch moves blocks in
