@@ -27,13 +27,15 @@ def _start_clock():
 # 2 - 20 s each on a box whose image is paged in and 30 - 120 s each on a cold one (measured: the same suite 351 s and 886 s on two boxes
 # of the pool, profiles/r06_gpu_suite*.txt) - and the driver kills the suite at 900 s, which would take the parity tests down with
 # them. So (1) those rehearsal tests run LAST, in order of what they prove, behind every parity test; (2) one of them is skipped - with
-# the reason - once so much of the limit is gone that a cold-box run of it (<= ~125 s seen) could cross it. On a warm box nothing is
-# skipped. OPV_SUITE_LIMIT_S overrides the 900 s.
+# the reason - once less than 200 s of the limit remain (a cold-box run of one took up to 121 s). On a warm box they start at ~300 s
+# and nothing is skipped; on the cold box of the record the last three would have been, and the suite would have ended at ~700 s.
+# OPV_SUITE_LIMIT_S overrides the 900 s.
 _LATE = ["test_world2_real_pipeline_every_global_stream_vs_oracle", "test_real_pipeline_rank_code_under_nccl_world_1",
          "test_gather_frames_under_nccl_world_1", "test_worldN_real_pipeline_over_rccl_every_global_stream_vs_oracle",
-         "test_bench_world2_under_the_drivers_launcher", "test_bench_world2_started_from_a_bare_shell", "test_bench_rccl_leg_executes_at_world_1",
+         "test_bench_world2_under_the_drivers_launcher", "test_bench_world2_started_from_a_bare_shell",
          "test_bench_worldN_over_rccl_under_the_drivers_launcher", "test_bench_world2_a_dead_rank_takes_the_job_down"]
-_LATE_RESERVE_S = 150.0
+# (test_bench_rccl_leg_executes_at_world_1 is not one of them: it only reads what the session-start child already did)
+_LATE_RESERVE_S = 200.0
 
 
 def _late_rank(item):
